@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference via oracle/ref_shim.py) on seeded synthetic weights + inputs (magicdance_amd.synthetic).
+
+Run in the build container only:   python -m oracle.make_golden [case ...]
+The fixtures pin oracle/restatement.py (tests/test_oracle_golden.py) and, through it, the HIP path.
+Large tensors (bank entries, pose residuals) are stored as a leading slice + summary statistics to keep the
+fixtures small; eps and the DDIM trajectory are stored in full.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+from magicdance_amd import synthetic  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+PREFIXES = dict(unet="model.diffusion_model.", app="appearance_control_model.", pose="pose_control_model.")
+
+CASES = {
+    # name: (net overrides, latent side, frames, t for the single apply_model probe, ddim steps)
+    "small_b1": (dict(model_channels=64, num_heads=2), 16, 1, 501, 10),
+    "small_b2": (dict(model_channels=64, num_heads=2), 16, 2, 741, 4),
+    "full_b1": (dict(), 8, 1, 981, 2),
+}
+
+
+def summarize(t):
+    t = t.detach().float()
+    flat = t.reshape(-1)
+    return np.array([flat.mean().item(), flat.std().item(), flat.abs().max().item(), flat.norm().item()], np.float64)
+
+
+def head_slice(t, n=4):
+    """first n tokens / first n rows of a [B,N,C] or [B,C,H,W] tensor."""
+    t = t.detach().float()
+    if t.dim() == 3:
+        return t[:, :n].contiguous().numpy()
+    return t[:, :, :1, :n].contiguous().numpy()
+
+
+def run_case(name):
+    geo, side, frames, t_probe, steps = CASES[name]
+    torch.manual_seed(0)
+    t0 = time.time()
+    m = ref_shim.build_reference_model(geo, image_size=side)
+    sd = {}
+    for pre, mod in [(PREFIXES["unet"], m.model.diffusion_model), (PREFIXES["app"], m.appearance_control_model),
+                     (PREFIXES["pose"], m.pose_control_model)]:
+        sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
+    m.load_state_dict(sd, strict=False)
+    inp = synthetic.synth_inputs((side, side), frames=frames, seed=0)
+    rep = lambda x: x.repeat(frames, 1, 1, 1) if x.dim() == 4 else x.repeat(frames, 1, 1)
+    # batched oracle recipe = train_tiktok.py:408-444: repeat ctx and the ref latent F times, one x_T per
+    # sample -- here the SAME x_T for every frame (test_any_image_pose.py:201-202).
+    ref, ctx, x_T, pose = rep(inp["ref"]), rep(inp["ctx"]), rep(inp["x_T"]), inp["pose"]
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
+    out = dict(geo_model_channels=geo.get("model_channels", 320), geo_num_heads=geo.get("num_heads", 8),
+               side=side, frames=frames, t_probe=t_probe, steps=steps, seed=0,
+               x_T=x_T.numpy(), ref=ref.numpy(), ctx_sum=summarize(ctx), pose_sum=summarize(pose))
+    t = torch.full((frames,), t_probe, dtype=torch.long)
+    with torch.no_grad():
+        bank = []
+        m.appearance_control_model(x=ref, hint=None, timesteps=t, context=ctx, attention_bank=bank,
+                                   attention_mode="write", uc=False)
+        for i, b in enumerate(bank):
+            out[f"bank{i}_head"], out[f"bank{i}_sum"] = head_slice(b[0]), summarize(b[0])
+        pr = m.pose_control_model(x=x_T, hint=pose, timesteps=t, context=ctx)
+        for i, p in enumerate(pr):
+            out[f"pose{i}_head"], out[f"pose{i}_sum"] = head_slice(p), summarize(p)
+        out["eps_c"] = m.apply_model(x_T, t, c, ref).numpy()
+        out["eps_u"] = m.apply_model(x_T, t, c, None, uc=True).numpy()
+        traj = []
+        z, _ = m.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=steps, eta=0.0,
+                            unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=x_T,
+                            img_callback=lambda pred_x0, i: traj.append(pred_x0.clone()))
+        out["z"] = z.numpy()
+        out["pred_x0_traj"] = torch.stack(traj).numpy()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(CASES)):
+        run_case(n)

@@ -1,0 +1,60 @@
+"""Shared test plumbing: seeded weights/inputs for a case, oracle runs, golden loading."""
+import os
+
+import numpy as np
+import torch
+
+from magicdance_amd import nets, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PREFIXES = dict(unet="model.diffusion_model.", app="appearance_control_model.", pose="pose_control_model.")
+
+
+def net_kwargs(model_channels=320, num_heads=8):
+    return dict(image_size=32, in_channels=4, model_channels=model_channels, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=num_heads, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+
+
+def build_nets(model_channels=320, num_heads=8, device="meta"):
+    kw = net_kwargs(model_channels, num_heads)
+    with torch.device(device):
+        unet = nets.ControlledUnetModelAttnPose(out_channels=4, **kw)
+        app = nets.ControlNetReferenceOnly(out_channels=4, hint_channels=3, **kw)
+        pose = nets.ControlNet(hint_channels=3, **kw)
+    return dict(unet=unet, app=app, pose=pose)
+
+
+def synth_weights(model_channels=320, num_heads=8, seed=0, device="cpu"):
+    mods = build_nets(model_channels, num_heads, "meta")
+    sd = {}
+    for k, m in mods.items():
+        sd.update(synthetic.synth_state_dict(m, PREFIXES[k], seed=seed, device=device))
+    return sd
+
+
+def load_golden(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def case_inputs(g):
+    """Rebuild the exact inputs of a golden case from its recorded seeds (and check the stored copies)."""
+    side, frames = int(g["side"]), int(g["frames"])
+    inp = synthetic.synth_inputs((side, side), frames=frames, seed=int(g["seed"]))
+    rep = lambda x: x.repeat(frames, *([1] * (x.dim() - 1)))
+    ref, ctx, x_T, pose = rep(inp["ref"]), rep(inp["ctx"]), rep(inp["x_T"]), inp["pose"]
+    assert np.array_equal(x_T.numpy(), g["x_T"]) and np.array_equal(ref.numpy(), g["ref"])
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
+    return dict(ref=ref, ctx=ctx, x_T=x_T, pose=pose, c=c, uc=uc)
+
+
+def summarize(t):
+    flat = t.detach().float().reshape(-1)
+    return np.array([flat.mean().item(), flat.std().item(), flat.abs().max().item(), flat.norm().item()], np.float64)
+
+
+def head_slice(t, n=4):
+    t = t.detach().float()
+    return (t[:, :n] if t.dim() == 3 else t[:, :, :1, :n]).contiguous().cpu().numpy()

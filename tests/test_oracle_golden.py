@@ -1,0 +1,54 @@
+"""CPU: pins oracle/restatement.py against vectors produced by the unmodified reference
+(oracle/make_golden.py).  fp32 vs fp32 on the same CPU kernels -> tolerance is rounding-level."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests import helpers as H
+
+CASES = ["small_b1", "small_b2", pytest.param("full_b1", marks=pytest.mark.slow)]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_restatement_matches_reference_golden(name):
+    g = H.load_golden(name)
+    mc, nh = int(g["geo_model_channels"]), int(g["geo_num_heads"])
+    sd = H.synth_weights(mc, nh, seed=int(g["seed"]))
+    cfg = R.Cfg(model_channels=mc, num_heads=nh)
+    inp = H.case_inputs(g)
+    assert np.allclose(H.summarize(inp["ctx"]), g["ctx_sum"]) and np.allclose(H.summarize(inp["pose"]), g["pose_sum"])
+    frames = int(g["frames"])
+    t = torch.full((frames,), int(g["t_probe"]), dtype=torch.long)
+    with torch.no_grad():
+        bank = R.appearance_forward(sd, R.APP, cfg, inp["ref"], t, inp["ctx"])
+        assert len(bank) == 16
+        for i, b in enumerate(bank):
+            np.testing.assert_allclose(H.head_slice(b[0]), g[f"bank{i}_head"], atol=2e-4, rtol=1e-4)
+            np.testing.assert_allclose(H.summarize(b[0]), g[f"bank{i}_sum"], atol=1e-4, rtol=1e-4)
+        pose = R.pose_forward(sd, R.POSE, cfg, inp["x_T"], inp["pose"], t, inp["ctx"])
+        assert len(pose) == 13
+        for i, p in enumerate(pose):
+            np.testing.assert_allclose(H.head_slice(p), g[f"pose{i}_head"], atol=2e-4, rtol=1e-4)
+            np.testing.assert_allclose(H.summarize(p), g[f"pose{i}_sum"], atol=1e-4, rtol=1e-4)
+        e_c = R.apply_model(sd, cfg, inp["x_T"], t, inp["c"], inp["ref"])
+        e_u = R.apply_model(sd, cfg, inp["x_T"], t, inp["c"], None, uc=True)
+        np.testing.assert_allclose(e_c.numpy(), g["eps_c"], atol=5e-5, rtol=1e-4)
+        np.testing.assert_allclose(e_u.numpy(), g["eps_u"], atol=5e-5, rtol=1e-4)
+        traj = []
+        z = R.ddim_sample(sd, cfg, inp["c"], inp["uc"], inp["x_T"], steps=int(g["steps"]), eta=0.0, scale=7.0,
+                          record=lambda i, d: traj.append(d["pred_x0"]))
+        scale = float(np.abs(g["z"]).max())
+        assert float(np.abs(z.numpy() - g["z"]).max()) <= 2e-5 * max(1.0, scale)
+        np.testing.assert_allclose(torch.stack(traj).numpy(), g["pred_x0_traj"], atol=2e-5 * max(1.0, scale), rtol=1e-4)
+
+
+def test_schedule_constants():
+    """ddim.py:359-388 / util.py:45-73 for the entry points' 50-step and BASELINE config-1's 20-step runs."""
+    ts = R.make_ddim_timesteps(50)
+    assert ts[0] == 1 and ts[-1] == 981 and len(ts) == 50
+    assert list(R.make_ddim_timesteps(20)[:3]) == [1, 51, 101]
+    ac = R.alphas_cumprod()
+    assert abs(float(ac[0]) - 0.99915) < 1e-6 and abs(float(ac[999]) - 0.0046602) < 1e-6
+    sig, a, ap = R.make_ddim_sampling_parameters(ac, ts, 0.0)
+    assert float(np.abs(sig).max()) == 0.0 and float(ap[0]) == float(ac[0]) and float(ap[1]) == float(a[0])

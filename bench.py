@@ -1,0 +1,156 @@
+"""bench.py -- headline benchmark of the MI355X hot path: 512x512 frames/s at 50 DDIM steps.
+
+A "step" (driver contract) = one pass of the hot path over one batch of synthetic input = sampling ONE batch of
+`--frames-per-gpu` frames through the full 50-step DDIM loop (appearance net + pose ControlNet + UNet cond/uncond +
+CFG/DDIM update per DDIM step), latents in -> latents out, inputs resident in HBM before the timed region.
+N=1 default workload = BASELINE.json configs[1]: single 512x512 frame, 50-step DDIM, full Appearance+Pose ControlNet,
+fp16, random-init (seeded synthetic) SD-1.5-geometry weights.  N>1: one process per GPU (torch.distributed over RCCL),
+frames sharded across ranks (weak scaling: `--frames-per-gpu` each), the reference-image attention bank broadcast from
+rank 0 per DDIM step, final latents all-gathered.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (igemm = the dominant kernel family, HIP-event timed per
+launch on the launch stream) and "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(device, size):
+    import magicdance_amd as M
+    from magicdance_amd import synthetic
+    cfg = M.cldm.load_config(M.DEFAULT_CONFIG)["model"]
+    cfg["params"]["first_stage_config"] = "__is_first_stage__"   # VAE / CLIP are outside the timed path
+    cfg["params"]["cond_stage_config"] = "__is_unconditional__"
+    cfg["params"]["image_size"] = size
+    with torch.device("meta"):
+        model = M.instantiate_from_config(cfg)
+    model = model.to_empty(device=device)
+    model.register_schedule(timesteps=1000, linear_start=cfg["params"]["linear_start"], linear_end=cfg["params"]["linear_end"])
+    model.logvar = torch.zeros(1000)
+    model = model.to(device)
+    with torch.no_grad():
+        for pre, mod in (("model.diffusion_model.", model.model.diffusion_model),
+                         ("appearance_control_model.", model.appearance_control_model),
+                         ("pose_control_model.", model.pose_control_model)):
+            sd = synthetic.synth_state_dict(mod, pre, seed=0, device=device)
+            mod.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=True)
+    return model.eval()
+
+
+def cpu_baseline(model, inp, size, max_seconds=40.0):
+    """The CPU oracle (oracle/restatement.py, torch fp32) on this box's host cores, bounded sample: ONE DDIM step
+    (cond + uncond apply_model) of the same single-frame workload; frames/s extrapolated to the full 50 steps."""
+    from oracle import restatement as R
+    sd = {}
+    for pre, mod in (("model.diffusion_model.", model.model.diffusion_model),
+                     ("appearance_control_model.", model.appearance_control_model),
+                     ("pose_control_model.", model.pose_control_model)):
+        sd.update({pre + k: v.detach().float().cpu() for k, v in mod.state_dict().items()})
+    cfg = R.Cfg()
+    c = {"c_concat": [inp["pose"][:1].cpu()], "c_crossattn": [inp["ctx"].cpu()], "image_control": [inp["ref"].cpu()],
+         "wonoise": True, "overlap_sampling": False}
+    x = inp["x_T"].cpu()
+    t = torch.full((1,), 981, dtype=torch.long)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        R.apply_model(sd, cfg, x, t, c, inp["ref"].cpu())
+        R.apply_model(sd, cfg, x, t, c, None, uc=True)
+        dt = time.time() - t0
+    return {"value": 1.0 / (50.0 * dt), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 50 DDIM steps (cond+uncond apply_model, 1 frame {8 * size}x{8 * size}) = {dt:.1f}s, x50 extrapolated"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed frame-batches (each = a full DDIM loop)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--size", type=int, default=64, help="latent side (64 = 512x512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from magicdance_amd import synthetic, ops
+    from magicdance_amd import parallel
+    model = build_model(dev, args.size)
+    fpg = args.frames_per_gpu
+    inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
+    runner = parallel.FrameShardedSampler(model, rank=rank, world=world)
+    my = slice(rank * fpg, (rank + 1) * fpg)
+    pose, ctx, ref, x_T = inp["pose"][my].contiguous(), inp["ctx"], inp["ref"], inp["x_T"].repeat(fpg, 1, 1, 1)
+
+    def one_batch():
+        return runner.sample(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
+
+    for _ in range(args.warmup):
+        one_batch()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        z = one_batch()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(z).all()), "non-finite latents"
+    frames = args.steps * fpg * world
+    out = {"metric": "512x512 frames/sec @ 50 DDIM steps", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "ms_per_ddim_step": 1e3 * dt / args.steps / args.ddim_steps,
+           "config": {"workload": f"configs[1]: {fpg} frame(s)/GPU {8 * args.size}x{8 * args.size}, {args.ddim_steps}-step DDIM, "
+                                  "appearance + pose ControlNet + UNet cond/uncond, CFG 7, latents in -> latents out",
+                      "frames_per_gpu": fpg, "ddim_steps": args.ddim_steps, "weights": "seeded synthetic, SD-1.5 geometry",
+                      "parallelism": f"frame-shard x{world}"}}
+    if rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of every kernel family over ONE un-captured DDIM step (same launch sequence)
+        fam = runner.profile_one_step(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
+        ig = fam["igemm"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one DDIM step)", "achieved": ach,
+                           "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": None,
+                           "launches": ig["launches"], "ms": ig["ms"]}
+        out["families_ms_per_ddim_step"] = {k: {"ms": v["ms"], "launches": v["launches"],
+                                                "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                                                "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
+                                            for k, v in fam.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, inp, args.size)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

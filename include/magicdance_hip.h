@@ -1,0 +1,183 @@
+/* magicdance_hip.h -- C ABI of libmagicdance_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (Boese0601/MagicDance) has NO native code and no FFI on its sampling hot path: every op is a
+ * PyTorch ATen call (cuDNN conv, cuBLAS GEMM, ATen group_norm/layer_norm/softmax) or xformers
+ * memory_efficient_attention.  The boundary a maintainer would bind is therefore the set of fused ops that the
+ * reference's Python modules imply; each entry point below cites the reference lines whose arithmetic it replaces
+ * (paths relative to model_lib/ControlNet/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers (contiguous), `stream`
+ * is a hipStream_t passed as void*.  Activations are NHWC fp16 ("token major": [B*H*W, C]); weights are fp16
+ * [N][K] with K contiguous.  Every launcher returns MD_OK (0) or a negative md_status; it never throws, never
+ * allocates, never synchronises (profiling mode excepted, see md_prof_*).
+ */
+#ifndef MAGICDANCE_HIP_H
+#define MAGICDANCE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MD_OK = 0,
+  MD_ERR_BAD_ARG = -1,     /* shape/alignment precondition violated */
+  MD_ERR_UNSUPPORTED = -2, /* configuration outside the hot path */
+  MD_ERR_WORKSPACE = -3,   /* workspace too small */
+  MD_ERR_HIP = -4          /* a HIP runtime call failed (md_last_hip_error() has the code) */
+} md_status;
+
+int md_version(void);            /* ABI version, bumps on any struct change */
+int md_last_hip_error(void);     /* hipError_t of the last failing runtime call */
+const char* md_arch(void);       /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * md_igemm: implicit-GEMM convolution / linear layer on the MFMA units with fused epilogue.
+ *   out[m][n] = epilogue( sum_k A(m,k) * w[n][k] ),  m = (b, oy, ox),  k = (tap, cin)
+ * Replaces: F.conv2d 3x3 / 1x1 in ResBlock (ldm/modules/diffusionmodules/openaimodel.py:221-252,261,275-295),
+ * Upsample/Downsample convs (:129-139, :171-180), torch.cat([h, skip]) feeding them (cldm/cldm.py:104-106, via
+ * the two-source A operand), SpatialTransformer proj_in/proj_out (ldm/modules/attention.py:343-361,366-385),
+ * to_q/to_k/to_v/to_out Linear (:155-162,171-174), GEGLU / FeedForward Linear (:50-77), ControlNet hint encoder
+ * and zero-convs (cldm/cldm.py:599-615, 733-734).
+ * ------------------------------------------------------------------------------------------------------- */
+enum { MD_ACT_NONE = 0, MD_ACT_SILU = 1, MD_ACT_GEGLU = 2 };
+
+typedef struct {
+  /* A operand: NHWC fp16, channel concat of up to two sources (a1 may be NULL, then c1 = 0) */
+  const void* a0;
+  const void* a1;
+  int32_t c0, c1;          /* channels per source; c0 % 8 == 0, c1 % 8 == 0 */
+  int32_t batch;           /* B */
+  int32_t hin, win;        /* source spatial size per sample */
+  int32_t hout, wout;      /* output spatial size per sample; M = batch*hout*wout */
+  int32_t ksize;           /* 1 or 3 (pad = ksize/2) */
+  int32_t stride;          /* 1 or 2 */
+  int32_t ups;             /* 1: nearest x2 upsample of the source before the conv (ksize 3, stride 1) */
+  /* weights */
+  const void* w;           /* fp16 [N][K], K = ksize*ksize*(c0+c1), k = tap*(c0+c1) + c */
+  int32_t n;               /* N, multiple of 4 */
+  /* epilogue */
+  const float* bias;       /* fp32 [N] (or [B][bias_batch_stride]) or NULL */
+  int64_t bias_batch_stride; /* 0: shared; else elements between per-sample bias vectors (time-embedding add) */
+  const void* res;         /* fp16 residual [M][ld_res] added after activation, or NULL */
+  int32_t ld_res;
+  int32_t act;             /* MD_ACT_* ; GEGLU: weights/bias rows interleaved a/gate in groups of 16, out width N/2 */
+  void* out;               /* fp16 (or fp32 if out_f32) [M][ld_out] */
+  int32_t ld_out;
+  int32_t out_f32;
+  /* optional transposed store of the trailing columns (V^T for attention): columns n >= n_tr_begin go to
+   * out_t[(b*(N-n_tr_begin) + (n-n_tr_begin)) * ld_t + tok], tok = oy*wout+ox.  n_tr_begin = N disables. */
+  void* out_t;
+  int32_t n_tr_begin;      /* multiple of 16 */
+  int32_t ld_t;
+  /* split-K workspace (fp32), may be NULL: then split-K is never chosen */
+  void* ws;
+  int64_t ws_bytes;
+  int32_t force_cfg;       /* -1 auto; otherwise tile config index (tests / tuning) */
+  int32_t force_splitk;    /* 0 auto; otherwise number of K splits */
+} md_igemm_params;
+
+int md_igemm(const md_igemm_params* p, void* stream);
+/* bytes of split-K workspace that guarantees the auto heuristic is never constrained for this shape */
+int64_t md_igemm_workspace_bytes(const md_igemm_params* p);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * md_attention: flash-style scaled-dot-product attention with up to two K/V segments (self tokens + appearance
+ * bank tokens), online softmax in fp32, MFMA QK^T and PV.
+ *   out[b, i, h*d:(h+1)*d] = softmax_j( q_i . k_j * scale ) v_j,   j over segment 0 then segment 1
+ * Replaces: CrossAttention._forward einsum/softmax/einsum (ldm/modules/attention.py:168-199) and
+ * xformers.ops.memory_efficient_attention (:225-250), including torch.cat([norm1(x)] + bank, dim=1) feeding
+ * attn1 in BasicTransformerBlock 'read' mode (:301-313): the concat is never materialised, the kernel walks two
+ * base pointers.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q;  int64_t q_batch_stride;  int32_t ld_q;     /* fp16 [B][Nq][ld_q], head h at column h*d */
+  const void* k0; int64_t k0_batch_stride; int32_t ld_k0;    /* fp16 [B][N0][ld_k0] */
+  const void* vt0; int64_t vt0_batch_stride; int32_t ld_vt0; /* fp16 V^T [B][H*d][ld_vt0] (token contiguous) */
+  int32_t n0;
+  const void* k1; int64_t k1_batch_stride; int32_t ld_k1;    /* second segment or NULL; batch stride 0 = shared */
+  const void* vt1; int64_t vt1_batch_stride; int32_t ld_vt1;
+  int32_t n1;
+  int32_t n1_batches;      /* samples b < n1_batches attend to segment 1; the rest only to segment 0 */
+  void* out; int64_t out_batch_stride; int32_t ld_out;       /* fp16 [B][Nq][ld_out] */
+  int32_t batch, heads, nq, d;  /* d in {40, 80, 160} (any multiple of 8 up to 160) */
+  float scale;             /* d^-0.5 */
+} md_attention_params;
+
+int md_attention(const md_attention_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * md_groupnorm: GroupNorm(G groups, fp32 statistics) + affine (+ SiLU) on NHWC fp16, optional two-source concat.
+ * Replaces: GroupNorm32 + SiLU (ldm/modules/diffusionmodules/util.py:252-254, openaimodel.py:221-225,245-252,
+ * 746-750) and Normalize (ldm/modules/attention.py:89-90).  `ws` needs md_groupnorm_workspace_bytes().
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x0; const void* x1; int32_t c0, c1;  /* NHWC fp16 sources (x1 may be NULL) */
+  int32_t batch, hw, groups;
+  float eps;
+  const float* gamma; const float* beta;            /* fp32 [c0+c1] */
+  int32_t silu;
+  void* out;                                        /* fp16 [B][hw][c0+c1] */
+  void* ws; int64_t ws_bytes;
+} md_groupnorm_params;
+int md_groupnorm(const md_groupnorm_params* p, void* stream);
+int64_t md_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);
+
+/* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 2048), fp32 statistics, eps 1e-5.
+ * Replaces nn.LayerNorm norm1/2/3 (ldm/modules/attention.py:270-272, 281-319). */
+int md_layernorm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
+                 float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Small fused element-wise / GEMV ops
+ * ------------------------------------------------------------------------------------------------------- */
+/* NCHW fp32 [B][C][H][W] -> NHWC fp16 [B][H][W][cpad] (channels >= C zero-filled). (stem / hint input) */
+int md_nchw_to_nhwc_f16(const float* x, void* out, int32_t batch, int32_t c, int32_t hw, int32_t cpad, void* stream);
+/* NHWC (fp16 or fp32, channel stride ld) -> NCHW fp32 */
+int md_nhwc_to_nchw_f32(const void* x, int32_t x_is_f32, float* out, int32_t batch, int32_t c, int32_t hw,
+                        int32_t ld, void* stream);
+/* out = a + b (fp16, n % 8 == 0); b_batch may broadcast: b index = i % b_period.  (pose residual adds,
+ * cldm/cldm.py:93-95,102-104; guided-hint add :744-747) */
+int md_add_f16(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream);
+/* sinusoidal timestep embedding (ldm/modules/diffusionmodules/util.py:189-209): out fp32 [nt][dim] */
+int md_timestep_embedding(const float* t, float* out, int32_t nt, int32_t dim, float max_period, void* stream);
+/* y[r][n] = bias[n] + sum_k act(x[r][k]) * w[n][k]; x fp32 [rows][k], w fp16 [n][k], y fp32; rows <= 64.
+ * act_in = 1 applies SiLU to x on load (emb_layers: SiLU -> Linear, openaimodel.py:238-244;
+ * time_embed MLP cldm/cldm.py:66-68). */
+int md_gemv_f32(const float* x, const void* w, const float* bias, float* y, int32_t rows, int32_t k, int32_t n,
+                int32_t act_in, void* stream);
+/* rows of a table -> fixed "current step" buffer: dst[i] = table[row*width + i]  (fp32) */
+int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, float* dst,
+                      int32_t width, void* stream);
+/* increments *counter by 1 (device side), used to advance the DDIM step inside a captured graph */
+int md_counter_add(int32_t* counter, int32_t delta, void* stream);
+
+/* Fused classifier-free-guidance combine + DDIM update (ldm/models/diffusion/ddim.py:605,617-645).
+ *   e = e_u + scale*(e_c - e_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);
+ *   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise
+ * eps_c/eps_u: NHWC fp32 [B][hw][ld_eps] (first 4 channels), x / x_prev / pred_x0 / noise: NCHW fp32 [B][C][hw].
+ * coef: device fp32 [5] = {a_t, a_prev, sigma_t, sqrt_one_minus_a_t, cfg_scale}. eps_u may be NULL (no CFG).
+ * eps_out (optional, NCHW fp32) receives the guided eps.  noise may be NULL when sigma == 0. */
+int md_ddim_update(const float* eps_c, const float* eps_u, int32_t ld_eps, const float* x, const float* noise,
+                   const float* coef, float* x_prev, float* pred_x0, float* eps_out, int32_t batch, int32_t c,
+                   int32_t hw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Runtime: HIP-graph capture of a launch sequence and per-kernel-family timing
+ * ------------------------------------------------------------------------------------------------------- */
+int md_graph_begin(void* stream);                  /* hipStreamBeginCapture (thread-local mode) */
+int md_graph_end(void* stream, void** graph_exec); /* end capture + instantiate */
+int md_graph_launch(void* graph_exec, void* stream);
+int md_graph_destroy(void* graph_exec);
+
+enum { MD_FAM_IGEMM = 0, MD_FAM_ATTENTION = 1, MD_FAM_NORM = 2, MD_FAM_ELEMENTWISE = 3, MD_FAM_COUNT = 4 };
+/* When enabled every launcher brackets its kernel(s) with HIP events on the launch stream (never under graph
+ * capture).  md_prof_collect synchronises, sums event times per family and clears the records. */
+int md_prof_enable(int32_t on);
+int md_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_per_family,
+                    double* bytes_per_family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

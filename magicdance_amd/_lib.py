@@ -1,0 +1,106 @@
+"""ctypes binding of libmagicdance_hip.so (the C ABI declared in include/magicdance_hip.h).
+
+The product path has no fallback: if the gfx950 library is missing or does not export a declared symbol,
+importing an op raises.  Build it with ``magicdance_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagicdance_hip.so")
+
+MD_OK = 0
+MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU = 0, 1, 2
+FAMILIES = ("igemm", "attention", "norm", "elementwise")
+STATUS = {0: "MD_OK", -1: "MD_ERR_BAD_ARG", -2: "MD_ERR_UNSUPPORTED", -3: "MD_ERR_WORKSPACE", -4: "MD_ERR_HIP"}
+
+
+class IgemmParams(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32), ("batch", C.c_int32),
+        ("hin", C.c_int32), ("win", C.c_int32), ("hout", C.c_int32), ("wout", C.c_int32), ("ksize", C.c_int32),
+        ("stride", C.c_int32), ("ups", C.c_int32), ("w", C.c_void_p), ("n", C.c_int32), ("bias", C.c_void_p),
+        ("bias_batch_stride", C.c_int64), ("res", C.c_void_p), ("ld_res", C.c_int32), ("act", C.c_int32),
+        ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32), ("out_t", C.c_void_p),
+        ("n_tr_begin", C.c_int32), ("ld_t", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("force_cfg", C.c_int32), ("force_splitk", C.c_int32),
+    ]
+
+
+class AttentionParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_batch_stride", C.c_int64), ("ld_q", C.c_int32),
+        ("k0", C.c_void_p), ("k0_batch_stride", C.c_int64), ("ld_k0", C.c_int32),
+        ("vt0", C.c_void_p), ("vt0_batch_stride", C.c_int64), ("ld_vt0", C.c_int32), ("n0", C.c_int32),
+        ("k1", C.c_void_p), ("k1_batch_stride", C.c_int64), ("ld_k1", C.c_int32),
+        ("vt1", C.c_void_p), ("vt1_batch_stride", C.c_int64), ("ld_vt1", C.c_int32), ("n1", C.c_int32),
+        ("n1_batches", C.c_int32),
+        ("out", C.c_void_p), ("out_batch_stride", C.c_int64), ("ld_out", C.c_int32),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("d", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32), ("batch", C.c_int32),
+        ("hw", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("silu", C.c_int32), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+# name -> (restype, argtypes): every symbol include/magicdance_hip.h declares
+SIGNATURES = {
+    "md_version": (C.c_int, []),
+    "md_last_hip_error": (C.c_int, []),
+    "md_arch": (C.c_char_p, []),
+    "md_igemm": (C.c_int, [C.POINTER(IgemmParams), _vp]),
+    "md_igemm_workspace_bytes": (_i64, [C.POINTER(IgemmParams)]),
+    "md_attention": (C.c_int, [C.POINTER(AttentionParams), _vp]),
+    "md_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), _vp]),
+    "md_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "md_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "md_nchw_to_nhwc_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "md_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "md_add_f16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "md_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
+    "md_gemv_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "md_select_row_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    "md_counter_add": (C.c_int, [_vp, _i32, _vp]),
+    "md_ddim_update": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "md_graph_begin": (C.c_int, [_vp]),
+    "md_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "md_graph_launch": (C.c_int, [_vp, _vp]),
+    "md_graph_destroy": (C.c_int, [_vp]),
+    "md_prof_enable": (C.c_int, [_i32]),
+    "md_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class MagicDanceHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MagicDanceHipError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is required (run magicdance_amd/csrc/build.sh or "
+            f"__graft_entry__.build()); there is no CPU/PyTorch fallback for the sampling hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != MD_OK:
+        lib = load()
+        raise MagicDanceHipError(f"{what} failed: {STATUS.get(rc, rc)} (hipError {lib.md_last_hip_error()})")

@@ -1,0 +1,232 @@
+// Small streaming / GEMV kernels of the sampling loop (gfx950): layout conversion at the NCHW-fp32 boundary of
+// apply_model, pose-residual adds, timestep embedding + embedding MLP GEMVs, per-step table selection for the
+// captured step graph, and the fused CFG + DDIM update.  All HBM/L2-bound, vectorised where the layout allows.
+#include "md_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f16(const float* __restrict__ x, half_t* __restrict__ out, int c,
+                                                        int hw, int cpad, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over [b][p][cpad]
+  if (i >= total) return;
+  const int cc = (int)(i % cpad);
+  const long long bp = i / cpad;
+  const int p = (int)(bp % hw);
+  const long long b = bp / hw;
+  out[i] = cc < c ? (half_t)x[(b * c + cc) * hw + p] : (half_t)0.f;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32(const void* __restrict__ x, float* __restrict__ out, int c,
+                                                        int hw, int ld, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over [b][c][p]
+  if (i >= total) return;
+  const int p = (int)(i % hw);
+  const long long bc = i / hw;
+  const int cc = (int)(bc % c);
+  const long long b = bc / c;
+  const long long src = (b * hw + p) * ld + cc;
+  out[i] = F32 ? reinterpret_cast<const float*>(x)[src] : (float)reinterpret_cast<const half_t*>(x)[src];
+}
+
+__global__ __launch_bounds__(256) void add_f16(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                               half_t* __restrict__ out, long long n8, long long period8) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < n8; i += stride) {
+    const h8 va = reinterpret_cast<const h8*>(a)[i];
+    const h8 vb = reinterpret_cast<const h8*>(b)[i % period8];
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)va[e] + (float)vb[e]);
+    reinterpret_cast<h8*>(out)[i] = o;
+  }
+}
+
+__global__ void timestep_embedding(const float* __restrict__ t, float* __restrict__ out, int nt, int dim,
+                                   float max_period) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= nt * dim) return;
+  const int r = i / dim, j = i - r * dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    const int f = j < half ? j : j - half;
+    // util.py:199-205: freqs = exp(-log(max_period) * arange(half) / half); emb = [cos(args), sin(args)]
+    const float freq = expf(-logf(max_period) * (float)f / (float)half);
+    const float arg = t[r] * freq;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[i] = v;
+}
+
+// y[r][n] = bias[n] + sum_k act(x[r][k]) w[n][k]; one wave per output column n, up to 8 rows per pass.
+template <int R>
+__global__ __launch_bounds__(256) void gemv_f32(const float* __restrict__ x, const half_t* __restrict__ w,
+                                                const float* __restrict__ bias, float* __restrict__ y, int rows, int k,
+                                                int n, int act_in) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 4 + wave;
+  if (col >= n) return;
+  const int r0 = blockIdx.y * R;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  const half_t* wr = w + (long long)col * k;
+  for (int kk = lane * 8; kk < k; kk += 64 * 8) {
+    const h8 wv = *reinterpret_cast<const h8*>(wr + kk);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r0 + r < rows) {
+        const float* xr = x + (long long)(r0 + r) * k + kk;
+        const f4 x0 = *reinterpret_cast<const f4*>(xr), x1 = *reinterpret_cast<const f4*>(xr + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = e < 4 ? x0[e] : x1[e - 4];
+          if (act_in) xv = md::silu_f(xv);
+          acc[r] += xv * (float)wv[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float s = md::wave_sum(acc[r]);
+    if (lane == 0 && r0 + r < rows) y[(long long)(r0 + r) * n + col] = s + (bias ? bias[col] : 0.f);
+  }
+}
+
+__global__ void select_row_f32(const float* __restrict__ table, const int* __restrict__ counter, int row_offset,
+                               float* __restrict__ dst, int width) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  const int row = (counter ? *counter : 0) + row_offset;
+  dst[i] = table[(long long)row * width + i];
+}
+
+__global__ void counter_add(int* counter, int delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *counter += delta;
+}
+
+__global__ __launch_bounds__(256) void ddim_update(const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                                   int ld_eps, const float* __restrict__ x,
+                                                   const float* __restrict__ noise, const float* __restrict__ coef,
+                                                   float* __restrict__ x_prev, float* __restrict__ pred_x0,
+                                                   float* __restrict__ eps_out, int c, int hw, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // NCHW index
+  if (i >= total) return;
+  const int p = (int)(i % hw);
+  const long long bc = i / hw;
+  const int cc = (int)(bc % c);
+  const long long b = bc / c;
+  const long long e_idx = (b * hw + p) * ld_eps + cc;
+  const float a_t = coef[0], a_prev = coef[1], sigma = coef[2], s1m = coef[3], scale = coef[4];
+  float e = eps_c[e_idx];
+  if (eps_u) {
+    const float eu = eps_u[e_idx];
+    e = eu + scale * (e - eu);  // ddim.py:605
+  }
+  const float xv = x[i];
+  const float px0 = (xv - s1m * e) / sqrtf(a_t);                      // ddim.py:624
+  const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;         // ddim.py:640
+  float xp = sqrtf(a_prev) * px0 + dir;                               // ddim.py:644
+  if (noise) xp += sigma * noise[i];
+  x_prev[i] = xp;
+  if (pred_x0) pred_x0[i] = px0;
+  if (eps_out) eps_out[i] = e;
+}
+
+}  // namespace
+
+extern "C" int md_nchw_to_nhwc_f16(const float* x, void* out, int32_t batch, int32_t c, int32_t hw, int32_t cpad,
+                                   void* stream) {
+  if (!x || !out || batch <= 0 || c <= 0 || hw <= 0 || cpad < c) return MD_ERR_BAD_ARG;
+  const long long total = (long long)batch * hw * cpad;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)total * 2.0 + (double)batch * c * hw * 4.0);
+  hipLaunchKernelGGL(nchw_to_nhwc_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, c, hw,
+                     cpad, total);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_nhwc_to_nchw_f32(const void* x, int32_t x_is_f32, float* out, int32_t batch, int32_t c, int32_t hw,
+                                   int32_t ld, void* stream) {
+  if (!x || !out || batch <= 0 || c <= 0 || hw <= 0 || ld < c) return MD_ERR_BAD_ARG;
+  const long long total = (long long)batch * hw * c;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)total * 8.0);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (x_is_f32)
+    hipLaunchKernelGGL(nhwc_to_nchw_f32<true>, grid, dim3(256), 0, s, x, out, c, hw, ld, total);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_f32<false>, grid, dim3(256), 0, s, x, out, c, hw, ld, total);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_add_f16(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream) {
+  if (!a || !b || !out || n <= 0 || (n & 7) || b_period <= 0 || (b_period & 7)) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)n * 6.0);
+  const long long n8 = n >> 3;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_f16, dim3((unsigned)blocks), dim3(256), 0, s, (const half_t*)a, (const half_t*)b, (half_t*)out,
+                     n8, (long long)(b_period >> 3));
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_timestep_embedding(const float* t, float* out, int32_t nt, int32_t dim, float max_period,
+                                     void* stream) {
+  if (!t || !out || nt <= 0 || dim <= 0) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)nt * dim * 4.0);
+  hipLaunchKernelGGL(timestep_embedding, dim3((nt * dim + 255) / 256), dim3(256), 0, s, t, out, nt, dim, max_period);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_gemv_f32(const float* x, const void* w, const float* bias, float* y, int32_t rows, int32_t k,
+                           int32_t n, int32_t act_in, void* stream) {
+  if (!x || !w || !y || rows <= 0 || rows > 1024 || k <= 0 || (k & 7) || n <= 0) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 2.0 * rows * (double)k * n, (double)n * k * 2.0);
+  hipLaunchKernelGGL(gemv_f32<8>, dim3((n + 3) / 4, (rows + 7) / 8), dim3(256), 0, s, x, (const half_t*)w, bias, y, rows,
+                     k, n, act_in);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, float* dst,
+                                 int32_t width, void* stream) {
+  if (!table || !dst || width <= 0) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)width * 8.0);
+  hipLaunchKernelGGL(select_row_f32, dim3((width + 255) / 256), dim3(256), 0, s, table, row_counter, row_offset, dst,
+                     width);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_counter_add(int32_t* counter, int32_t delta, void* stream) {
+  if (!counter) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(counter_add, dim3(1), dim3(64), 0, s, counter, delta);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_ddim_update(const float* eps_c, const float* eps_u, int32_t ld_eps, const float* x,
+                              const float* noise, const float* coef, float* x_prev, float* pred_x0, float* eps_out,
+                              int32_t batch, int32_t c, int32_t hw, void* stream) {
+  if (!eps_c || !x || !coef || !x_prev || batch <= 0 || c <= 0 || hw <= 0 || ld_eps < c) return MD_ERR_BAD_ARG;
+  const long long total = (long long)batch * c * hw;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)total * 4.0 * 5.0);
+  hipLaunchKernelGGL(ddim_update, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, eps_c, eps_u, ld_eps, x, noise,
+                     coef, x_prev, pred_x0, eps_out, c, hw, total);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}

@@ -1,0 +1,345 @@
+"""DDIM sampler of the reference-attention + pose model.
+
+Mirror of ``DDIMSampler_ReferenceOnly`` (model_lib/ControlNet/ldm/models/diffusion/ddim.py:346-729): same
+``make_schedule`` / ``sample`` / ``ddim_sampling`` / ``p_sample_ddim`` signatures and branch structure
+(:537-605).  Two execution routes:
+
+  * generic: one ``apply_model`` per branch exactly as the reference orders them (any cond layout, eta > 0,
+    callbacks, masks) -- every op still runs in the HIP kernels;
+  * fused (the entry points' configuration: "controlnet is more important" CFG branch :595-605, ``wonoise``,
+    eta == 0): per step ONE captured HIP graph = appearance net (once, batch 1 when all reference latents are
+    equal) + pose ControlNet + the UNet's cond and uncond passes batched as 2B samples (they share all weights)
+    + fused CFG/DDIM update; the timestep and schedule coefficients are read from device tables indexed by a
+    device-side counter, so 50 steps are 50 graph launches with no host work in between.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import F16, F32
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """ldm/modules/diffusionmodules/util.py:45-59."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ddim_timesteps + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """util.py:62-73 (alphacums: fp32 numpy/torch cpu array)."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+class DDIMSampler_ReferenceOnly(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        """ddim.py:359-388 (host-side fp32 numpy; the device only sees the per-step coefficient table)."""
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        ac = self.model.alphas_cumprod.detach().cpu().numpy().astype(np.float32)
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = make_ddim_sampling_parameters(
+            ac, self.ddim_timesteps, ddim_eta, verbose)
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - self.ddim_alphas)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, inpaint=None, **kwargs):
+        """ddim.py:391-458."""
+        if inpaint is not None or mask is not None or score_corrector is not None or quantize_x0 or dynamic_threshold:
+            raise NotImplementedError("inpaint / mask / score-corrector variants are outside the pose hot path")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, x_T=x_T,
+                                  log_every_t=log_every_t, temperature=temperature, noise_dropout=noise_dropout,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, ucg_schedule=ucg_schedule)
+
+    # ------------------------------------------------------------------ loop (ddim.py:461-516)
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100, temperature=1.,
+                      noise_dropout=0., unconditional_guidance_scale=1., unconditional_conditioning=None,
+                      ucg_schedule=None, force_generic=False):
+        device = self.model.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.detach().to(device=device, dtype=F32)
+        timesteps = self.ddim_timesteps
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+
+        if (not force_generic and ucg_schedule is None and noise_dropout == 0.
+                and self._fused_ok(cond, unconditional_conditioning, unconditional_guidance_scale)):
+            return self._fused_sampling(cond, img, unconditional_guidance_scale, callback, img_callback, log_every_t,
+                                        intermediates)
+
+        for i, step in enumerate(time_range):
+            index = total_steps - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            if ucg_schedule is not None:
+                assert len(ucg_schedule) == len(time_range)
+                unconditional_guidance_scale = ucg_schedule[i]
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                              noise_dropout=noise_dropout,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    # ------------------------------------------------------------------ one step, generic (ddim.py:519-645)
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, temperature=1., noise_dropout=0.,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None):
+        model, device = self.model, self.model.device
+        b = x.shape[0]
+        reference_image_noisy = None
+        if c.get("image_control") is not None:
+            start = torch.cat(c["image_control"], 1)
+            reference_image_noisy = start if c["wonoise"] else model.q_sample(start.to(device), t)   # :529-535
+        uc = unconditional_conditioning
+        eps_u = None
+        if uc is None or unconditional_guidance_scale == 1.:
+            eps_c = model.apply_model_nhwc(x, t, c, reference_image_noisy)                           # :537-538
+        elif uc.get("image_control") is not None:                                                    # "balance" :540-567
+            x_in, t_in = torch.cat([x] * 2), torch.cat([t] * 2)
+            ref_in = torch.cat([reference_image_noisy] * 2)
+            c_in = dict()
+            for k in c:
+                if isinstance(c[k], list):
+                    c_in[k] = [torch.cat([uc[k][i], c[k][i]]) for i in range(len(c[k]))]
+                else:
+                    c_in[k] = c[k]
+            eps_u, eps_c = model.apply_model_nhwc(x_in, t_in, c_in, ref_in).chunk(2)
+        else:                                                                                        # :595-605
+            if c.get("overlap_sampling"):
+                raise NotImplementedError("overlap_sampling (temporal window) is not reachable from the entry points")
+            eps_c = model.apply_model_nhwc(x, t, c, reference_image_noisy).clone()   # arena is rewound below
+            eps_u = model.apply_model_nhwc(x, t, c, None, uc=True)
+        coef = torch.tensor([self.ddim_alphas[index], self.ddim_alphas_prev[index], self.ddim_sigmas[index],
+                             self.ddim_sqrt_one_minus_alphas[index], unconditional_guidance_scale],
+                            dtype=F32, device=device)
+        sigma = float(self.ddim_sigmas[index])
+        noise = None
+        if sigma != 0.0:
+            noise = torch.randn_like(x) if not repeat_noise else torch.randn_like(x[:1]).repeat(b, 1, 1, 1)
+            noise = (noise * temperature).contiguous()
+            if noise_dropout > 0.:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        hw = x.shape[2] * x.shape[3]
+        cch = x.shape[1]
+        x = x.detach().to(device=device, dtype=F32).contiguous()
+        x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+        ops.ddim_update(eps_c, eps_u, eps_c.shape[-1], x, noise, coef, x_prev, pred_x0, None, b, cch, hw)
+        return x_prev, pred_x0
+
+    # ------------------------------------------------------------------ fused route
+    def _fused_ok(self, c, uc, scale):
+        if uc is None or scale == 1. or not isinstance(c, dict):
+            return False
+        if uc.get("image_control") is not None or c.get("overlap_sampling"):
+            return False
+        if c.get("image_control") is None or c.get("c_concat") is None or not c.get("wonoise"):
+            return False
+        if c.get("c_crossattn_void") is not None:
+            return False
+        return float(np.abs(self.ddim_sigmas).max()) == 0.0
+
+    def _fused_sampling(self, c, img, scale, callback, img_callback, log_every_t, intermediates):
+        model = self.model
+        st = model._fused
+        if st is None:
+            st = model._fused = FusedStepRunner(model)
+        total = self.ddim_timesteps.shape[0]
+        # graph capture is illegal on the legacy default stream: the fused route runs on its own stream
+        caller = torch.cuda.current_stream()
+        st.stream.wait_stream(caller)
+        with torch.cuda.stream(st.stream):
+            st.prepare(c, img, self, scale)
+            for i in range(total):
+                st.step()
+                index = total - i - 1
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(st.pred_x0.clone(), i)
+                if index % log_every_t == 0 or index == total - 1:
+                    intermediates["x_inter"].append(st.x.clone())
+                    intermediates["pred_x0"].append(st.pred_x0.clone())
+            out = st.x.clone()
+        caller.wait_stream(st.stream)
+        return out, intermediates
+
+
+class FusedStepRunner:
+    """Owns the persistent device buffers of the fused step and its captured HIP graph (re-used across frames and
+    sample_log calls while shapes / context / step count stay the same).
+
+    bank modes:
+      inline : the appearance net runs inside every step graph (single call, nothing amortised)
+      table  : the banks of all S steps live in ``bank_table`` [S, bank_elems] (they depend on (ref, t, ctx) only,
+               never on the frame); the step graph copies row ``counter`` into ``bank_cur`` and skips the appearance
+               net.  Used for multi-GPU frame sharding (rows computed round-robin across ranks and broadcast over
+               RCCL, magicdance_amd/parallel.py) and for multi-frame sequences sharing one reference image.
+    """
+
+    def __init__(self, model):
+        self.model = model
+        self.key = None
+        self.graph = None
+        self.use_graph = True
+        self.table_mode = False
+        self.stream = torch.cuda.Stream(device=model.device)
+
+    def _same_rows(self, t):
+        return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
+
+    def prepare(self, c, x_T, sampler, scale, table_mode=False):
+        model, dev = self.model, self.model.device
+        app, pose_e, unet = model.engines()
+        b, cch, hh, ww = x_T.shape
+        ref = torch.cat(c["image_control"], 1).detach().to(device=dev, dtype=F32)
+        if ref.shape[0] > 1 and self._same_rows(ref):
+            ref = ref[:1]          # every frame shares the reference latent: one appearance pass, bank broadcast
+        ref = ref.contiguous()
+        ctx = torch.cat(c["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
+        if ctx.shape[0] > 1 and self._same_rows(ctx):
+            ctx = ctx[:1]
+        ctx_app = ctx if ctx.shape[0] in (1, ref.shape[0]) else ctx[:ref.shape[0]]
+        ctx_unet = ctx if ctx.shape[0] == 1 else torch.cat([ctx, ctx], 0)
+        hint = torch.cat(c["c_concat"], 1)
+        S = sampler.ddim_timesteps.shape[0]
+        # the context K/V caches are keyed on the tensor passed in; keep stable tensors across calls
+        if getattr(self, "_ctx_src", None) is None or not (self._ctx_src.shape == ctx.shape and torch.equal(self._ctx_src, ctx)):
+            self._ctx_src = ctx.clone()
+            self._ctx_app, self._ctx_unet = ctx_app.contiguous().clone(), ctx_unet.contiguous().clone()
+        self.kv_app = app.context_kv(self._ctx_app)
+        self.kv_pose = pose_e.context_kv(self._ctx_app if self._ctx_app.shape[0] in (1, b) else self._ctx_src)
+        self.kv_unet = unet.context_kv(self._ctx_unet)
+        key = (b, cch, hh, ww, S, ref.shape[0], tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
+               self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
+        if key != self.key:
+            self._allocate(key, b, cch, hh, ww, S, ref.shape[0], table_mode)
+        self.ref.copy_(ref)
+        self.x.copy_(x_T)
+        hf = pose_e.hint_features(hint)
+        if self.hint_feat is None or self.hint_feat.t.shape != hf.t.shape:
+            self.hint_feat = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
+            self._drop_graph()
+        self.hint_feat.t.copy_(hf.t)
+        # per-step tables: timestep (as float, repeated for the 2B-sample UNet batch) and DDIM coefficients
+        steps = np.flip(sampler.ddim_timesteps).astype(np.float32)
+        idx = np.arange(S)[::-1]
+        coef = np.stack([sampler.ddim_alphas[idx], sampler.ddim_alphas_prev[idx], sampler.ddim_sigmas[idx],
+                         sampler.ddim_sqrt_one_minus_alphas[idx], np.full(S, scale)], 1).astype(np.float32)
+        self.ts_table.copy_(torch.from_numpy(np.repeat(steps[:, None], self.ts_table.shape[1], 1).copy()))
+        self.coef_table.copy_(torch.from_numpy(coef))
+        self.counter.zero_()
+
+    def _drop_graph(self):
+        if self.graph is not None:
+            self.graph.destroy()
+            self.graph = None
+
+    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
+        from .nets import bank_shapes
+        dev = self.model.device
+        self._drop_graph()
+        self.key, self.table_mode = key, table_mode
+        self.b, self.cch, self.hw, self.S = b, cch, hh * ww, S
+        self.x = torch.empty((b, cch, hh, ww), dtype=F32, device=dev)
+        self.pred_x0 = torch.empty_like(self.x)
+        self.ref = torch.empty((bref, cch, hh, ww), dtype=F32, device=dev)
+        self.hint_feat = None
+        self.ts_table = torch.empty((S, 2 * b), dtype=F32, device=dev)
+        self.coef_table = torch.empty((S, 5), dtype=F32, device=dev)
+        self.t_cur = torch.empty((2 * b,), dtype=F32, device=dev)
+        self.coef_cur = torch.empty((5,), dtype=F32, device=dev)
+        self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.bank_table = self.bank_cur = None
+        if table_mode:
+            app = self.model.engines()[0]
+            self.bank_geo, off = [], 0
+            for n, c in bank_shapes(app.cfg, (hh, ww)):
+                self.bank_geo.append((off, bref, n, c))
+                off += bref * n * c
+            self.bank_elems = (off + 63) & ~63
+            self.bank_table = torch.empty((S, self.bank_elems), dtype=F16, device=dev)
+            self.bank_cur = torch.empty((self.bank_elems,), dtype=F16, device=dev)
+
+    def _bank_views(self, flat):
+        from .engine import Act
+        return [Act(flat[off:off + bb * n * c].view(bb, n, c), bb, 1, n, c) for off, bb, n, c in self.bank_geo]
+
+    def compute_bank_rows(self, rows):
+        """Run the appearance net for DDIM steps ``rows`` (indices into the flipped timestep order) and store each
+        step's 16 bank tensors in ``bank_table[row]``."""
+        app = self.model.engines()[0]
+        for r in rows:
+            app.arena.reset()
+            t_dev = self.ts_table[r, :self.ref.shape[0]].contiguous()
+            app.appearance(self.ref, t_dev, self.kv_app, bank_out=self._bank_views(self.bank_table[r]))
+
+    def _launch_sequence(self):
+        """One DDIM step as a fixed launch sequence on fixed addresses."""
+        model = self.model
+        app, pose_e, unet = model.engines()
+        b = self.b
+        ops.select_row_f32(self.ts_table, self.counter, 0, self.t_cur, 2 * b)
+        ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5)
+        arena = unet.arena
+        arena.reset()
+        if self.table_mode:
+            ops.select_row_f32(self.bank_table.view(F32), self.counter, 0, self.bank_cur.view(F32), self.bank_elems // 2)
+            banks = self._bank_views(self.bank_cur)
+        else:
+            banks = app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
+        pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
+        eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                        only_mid_control=model.only_mid_control)
+        oc = unet.cfg.out_channels
+        ops.ddim_update(eps[:b], eps[b:], oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
+        ops.counter_add(self.counter, 1)
+
+    def step(self):
+        if not self.use_graph:
+            self._launch_sequence()
+            return
+        if self.graph is None:
+            # warm-up pass sizes the arena (allocation is illegal under capture); it advances x, so restore after
+            x0, c0 = self.x.clone(), self.counter.clone()
+            self._launch_sequence()
+            torch.cuda.current_stream().synchronize()
+            self.x.copy_(x0)
+            self.counter.copy_(c0)
+            arena = self.model.engines()[2].arena
+            g = ops.Graph()
+            arena.frozen = True
+            try:
+                g.begin()
+                self._launch_sequence()
+                g.end()
+            finally:
+                arena.frozen = False
+            self.graph = g
+        self.graph.launch()

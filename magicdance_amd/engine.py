@@ -1,0 +1,571 @@
+"""Host side of the MI355X engine: packs the fp32 master weights of a hot-path network into the kernel layouts
+(fp16 [N][K], NHWC tap order, fused QKV, GEGLU-interleaved FF) and walks the network topology issuing the
+C-ABI launches of include/magicdance_hip.h.  Activations live in an arena (NHWC fp16, token-major), so a whole
+DDIM step is a fixed sequence of launches on fixed addresses and can be captured in one HIP graph.
+
+Topology / arithmetic follow the reference (paths relative to model_lib/ControlNet/):
+  ControlledUnetModelAttnPose.forward   cldm/cldm.py:59-112
+  ControlNetReferenceOnly.forward       cldm/cldm.py:469-497
+  ControlNet.forward                    cldm/cldm.py:736-757
+  TimestepEmbedSequential / ResBlock    ldm/modules/diffusionmodules/openaimodel.py:79-108, 275-295
+  SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU   ldm/modules/attention.py:366-385, 278-320, 168-199, 50-77
+There is no CPU path: every op raises if libmagicdance_hip.so is missing.
+"""
+import torch
+
+from . import ops
+from .ops import MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU
+
+F16, F32 = torch.float16, torch.float32
+_ES = {torch.float16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1}
+
+
+# ----------------------------------------------------------------------------------------------- arena
+class Arena:
+    """Bump allocator over large device blocks.  ``reset()`` rewinds; the same call sequence then yields the
+    same addresses, which is what makes the launch sequence graph-capturable."""
+
+    def __init__(self, device, block_bytes=512 << 20):
+        self.device, self.block_bytes = device, block_bytes
+        self.blocks, self.cur, self.off = [], 0, 0
+        self.frozen = False
+
+    def reset(self):
+        self.cur, self.off = 0, 0
+
+    def alloc(self, shape, dtype=F16, zero=False):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        es = _ES[dtype]
+        nbytes = (n * es + 255) & ~255
+        while True:
+            if self.cur < len(self.blocks) and self.off + nbytes <= self.blocks[self.cur].numel():
+                break
+            if self.cur < len(self.blocks):
+                self.cur, self.off = self.cur + 1, 0
+                continue
+            if self.frozen:
+                raise RuntimeError("arena grew during graph capture (warm up with the same shapes first)")
+            self.blocks.append(torch.empty(max(self.block_bytes, nbytes), dtype=torch.uint8, device=self.device))
+        t = self.blocks[self.cur][self.off:self.off + n * es].view(dtype).view(*shape)
+        self.off += nbytes
+        if zero:
+            t.zero_()
+        return t
+
+
+_ARENAS = {}
+
+
+def get_arena(device):
+    key = str(device)
+    if key not in _ARENAS:
+        _ARENAS[key] = Arena(device)
+    return _ARENAS[key]
+
+
+_WS = {}
+
+
+def get_workspace(device, nbytes=128 << 20):
+    """Split-K slabs / GroupNorm partials (shared scratch; kernels on one stream serialise their use)."""
+    key = str(device)
+    if key not in _WS or _WS[key].numel() < nbytes:
+        _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _WS[key]
+
+
+# ----------------------------------------------------------------------------------------------- packing
+def _h(t, device):
+    return t.detach().to(device=device, dtype=F16).contiguous()
+
+
+def _f(t, device):
+    return t.detach().to(device=device, dtype=F32).contiguous()
+
+
+def pack_conv(w, device, cin_pad=None):
+    """OIHW fp32 -> fp16 [O][kh*kw*I] with k = tap*I + c (NHWC gather order)."""
+    o, i, kh, kw = w.shape
+    w = w.detach().to(device=device, dtype=F32).permute(0, 2, 3, 1)  # O, kh, kw, I
+    if cin_pad is not None and cin_pad > i:
+        w = torch.nn.functional.pad(w, (0, cin_pad - i))
+    return w.reshape(o, -1).to(F16).contiguous()
+
+
+def pack_geglu(w, b, device):
+    """ff.net.0.proj [8C, C]: rows [a | gate] -> 16-row interleave [a0..15, g0..15, a16..31, ...] so the GEGLU
+    product is formed inside one lane's accumulators (igemm.hip epilogue)."""
+    half = w.shape[0] // 2
+    assert half % 16 == 0
+    wa, wg = w[:half].reshape(half // 16, 16, -1), w[half:].reshape(half // 16, 16, -1)
+    wp = torch.stack([wa, wg], dim=1).reshape(2 * half, -1)
+    ba, bg = b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)
+    bp = torch.stack([ba, bg], dim=1).reshape(2 * half)
+    return _h(wp, device), _f(bp, device)
+
+
+class Act:
+    """NHWC fp16 activation handle: tensor [B, H*W, C] + spatial dims."""
+    __slots__ = ("t", "b", "h", "w", "c")
+
+    def __init__(self, t, b, h, w, c):
+        self.t, self.b, self.h, self.w, self.c = t, b, h, w, c
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+    def head(self, nb):
+        """first nb samples (batch is the outermost dim, so this is a contiguous prefix)"""
+        return Act(self.t[:nb], nb, self.h, self.w, self.c)
+
+
+def _require_gpu(device):
+    """The hot path exists only as HIP kernels: refuse any other device and any missing extension, loudly."""
+    if device.type != "cuda":
+        raise RuntimeError("the MagicDance hot path runs on an MI355X (cuda/HIP device); move the model with "
+                           ".cuda() first -- there is no CPU implementation")
+    ops._lib.load()
+
+
+class NetEngine:
+    def __init__(self, net):
+        self.kind, self.cfg = net.kind, net.cfg
+        p = next(net.parameters())
+        _require_gpu(p.device)
+        self.device = p.device
+        self.arena = get_arena(self.device)
+        self.heads_cfg = (net.cfg.num_heads, net.cfg.num_head_channels)
+        self._pack(net)
+        self._ctx_cache = None
+        self._hint_cache = None
+        self._bank_out = None
+        self._write_stop_at = sum(len(st["blocks"]) for st in self._all_st()) if self.kind == "appearance" else -1
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack(self, net):
+        d = self.device
+        emb_w, emb_b = [], []
+        self.emb_total = 0
+
+        def pack_res(m):
+            r = dict(kind="res", cin=m.channels, cout=m.out_channels)
+            r["gn1"] = (_f(m.in_layers[0].weight, d), _f(m.in_layers[0].bias, d))
+            r["conv1_w"] = pack_conv(m.in_layers[2].weight, d)
+            # conv1 bias is folded into the time-embedding projection bias: h + bias + emb_out (openaimodel.py:284-294)
+            r["emb_off"] = self.emb_total
+            emb_w.append(m.emb_layers[1].weight.detach())
+            emb_b.append(m.emb_layers[1].bias.detach() + m.in_layers[2].bias.detach())
+            self.emb_total += m.out_channels
+            r["gn2"] = (_f(m.out_layers[0].weight, d), _f(m.out_layers[0].bias, d))
+            r["conv2_w"], r["conv2_b"] = pack_conv(m.out_layers[3].weight, d), _f(m.out_layers[3].bias, d)
+            if isinstance(m.skip_connection, torch.nn.Conv2d):
+                r["skip_w"], r["skip_b"] = pack_conv(m.skip_connection.weight, d), _f(m.skip_connection.bias, d)
+            return r
+
+        def pack_st(m):
+            c = m.proj_in.out_channels
+            s = dict(kind="st", c=m.in_channels, inner=c, heads=m.n_heads, dh=m.d_head)
+            s["gn"] = (_f(m.norm.weight, d), _f(m.norm.bias, d))
+            s["pin_w"], s["pin_b"] = pack_conv(m.proj_in.weight, d), _f(m.proj_in.bias, d)
+            s["pout_w"], s["pout_b"] = pack_conv(m.proj_out.weight, d), _f(m.proj_out.bias, d)
+            blocks = []
+            for blk in m.transformer_blocks:
+                t = {}
+                for i, ln in ((1, blk.norm1), (2, blk.norm2), (3, blk.norm3)):
+                    t[f"ln{i}"] = (_f(ln.weight, d), _f(ln.bias, d))
+                a1, a2 = blk.attn1, blk.attn2
+                t["qkv_w"] = _h(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d)  # [3C, C]
+                t["o1_w"], t["o1_b"] = _h(a1.to_out[0].weight, d), _f(a1.to_out[0].bias, d)
+                t["q2_w"] = _h(a2.to_q.weight, d)
+                t["kv2_w"] = _h(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d)                  # [2C, ctx]
+                t["o2_w"], t["o2_b"] = _h(a2.to_out[0].weight, d), _f(a2.to_out[0].bias, d)
+                t["ff1_w"], t["ff1_b"] = pack_geglu(blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach(), d)
+                t["ff2_w"], t["ff2_b"] = _h(blk.ff.net[2].weight, d), _f(blk.ff.net[2].bias, d)
+                blocks.append(t)
+            s["blocks"] = blocks
+            return s
+
+        def pack_layer(m):
+            name = type(m).__name__
+            if name == "ResBlock":
+                return pack_res(m)
+            if name == "SpatialTransformer":
+                return pack_st(m)
+            if name == "Downsample":
+                return dict(kind="down", c=m.channels, w=pack_conv(m.op.weight, d), b=_f(m.op.bias, d))
+            if name == "Upsample":
+                return dict(kind="up", c=m.channels, w=pack_conv(m.conv.weight, d), b=_f(m.conv.bias, d))
+            if isinstance(m, torch.nn.Conv2d):  # stem: 4 -> model_channels, input padded to 8 channels
+                return dict(kind="stem", cout=m.out_channels, w=pack_conv(m.weight, d, cin_pad=8), b=_f(m.bias, d))
+            raise NotImplementedError(name)
+
+        self.input_blocks = [[pack_layer(m) for m in blk] for blk in net.input_blocks]
+        self.middle_block = [pack_layer(m) for m in net.middle_block]
+        self.output_blocks = [[pack_layer(m) for m in blk] for blk in net.output_blocks] if hasattr(net, "output_blocks") else []
+        self.emb_w = _h(torch.cat(emb_w, 0), d)          # [sum Cout, 4*mc]
+        self.emb_b = _f(torch.cat(emb_b, 0), d)
+        self.te0_w, self.te0_b = _h(net.time_embed[0].weight, d), _f(net.time_embed[0].bias, d)
+        self.te2_w, self.te2_b = _h(net.time_embed[2].weight, d), _f(net.time_embed[2].bias, d)
+        if self.kind == "unet":
+            self.head_gn = (_f(net.out[0].weight, d), _f(net.out[0].bias, d))
+            self.head_w, self.head_b = pack_conv(net.out[2].weight, d), _f(net.out[2].bias, d)
+        if self.kind == "pose":
+            convs = [m for m in net.input_hint_block if isinstance(m, torch.nn.Conv2d)]
+            self.hint = [dict(w=pack_conv(m.weight, d, cin_pad=8 if i == 0 else None), b=_f(m.bias, d),
+                              stride=m.stride[0], cin=(8 if i == 0 else m.in_channels), cout=m.out_channels)
+                         for i, m in enumerate(convs)]
+            self.zero_convs = [dict(w=pack_conv(z[0].weight, d), b=_f(z[0].bias, d)) for z in net.zero_convs]
+            self.mid_out = dict(w=pack_conv(net.middle_block_out[0].weight, d), b=_f(net.middle_block_out[0].bias, d))
+
+    # ------------------------------------------------------------------ small helpers
+    def _ws(self):
+        return get_workspace(self.device)
+
+    def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
+             out_f32=False, out=None):
+        """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act."""
+        hin, win = x.h, x.w
+        if ups:
+            hout, wout = 2 * hin, 2 * win
+        elif stride == 2:
+            hout, wout = (hin + 1) // 2, (win + 1) // 2
+        else:
+            hout, wout = hin, win
+        nout = n // 2 if act == MD_ACT_GEGLU else n
+        if out is None:
+            out = self.arena.alloc((x.b, hout * wout, nout), F32 if out_f32 else F16)
+        ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
+                  a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
+                  res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
+                  out_f32=out_f32, ws=self._ws())
+        return Act(out, x.b, hout, wout, nout)
+
+    def gn(self, x, gb, *, x1=None, eps=1e-5, silu=True):
+        c = x.c + (0 if x1 is None else x1.c)
+        out = self.arena.alloc((x.b, x.hw, c), F16)
+        ops.groupnorm(x.t, gb[0], gb[1], out, self._ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
+                      c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu)
+        return Act(out, x.b, x.h, x.w, c)
+
+    def ln(self, x, gb, out=None):
+        if out is None:
+            out = self.arena.alloc((x.b, x.hw, x.c), F16)
+        ops.layernorm(x.t, gb[0], gb[1], out, x.b * x.hw, x.c)
+        return Act(out, x.b, x.h, x.w, x.c)
+
+    # ------------------------------------------------------------------ embeddings
+    def time_embedding(self, t_dev, nb):
+        """timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers in one GEMV
+        (util.py:189-209, cldm.py:66-68, openaimodel.py:238-244).  t_dev: fp32 [nb] on device.
+        Returns fp32 [nb, emb_total] = conv1.bias + emb_layers(SiLU(emb))."""
+        mc, ted = self.cfg.model_channels, self.cfg.time_embed_dim
+        a = self.arena
+        sin = ops.timestep_embedding(t_dev, a.alloc((nb, mc), F32), nb, mc)
+        e0 = ops.gemv_f32(sin, self.te0_w, self.te0_b, a.alloc((nb, ted), F32), nb, mc, ted, act_in=False)
+        e1 = ops.gemv_f32(e0, self.te2_w, self.te2_b, a.alloc((nb, ted), F32), nb, ted, ted, act_in=True)
+        return ops.gemv_f32(e1, self.emb_w, self.emb_b, a.alloc((nb, self.emb_total), F32), nb, ted, self.emb_total,
+                            act_in=True)
+
+    # ------------------------------------------------------------------ context / hint (step-invariant)
+    def context_kv(self, ctx):
+        """Cross-attention K / V^T of every transformer block for a text context [Bc, T, ctx_dim] (fp32/fp16 torch
+        tensor).  Step- and frame-invariant, so cached per context tensor (attention.py:171-174 to_k/to_v)."""
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        if self._ctx_cache is not None and self._ctx_cache[0] == key:
+            return self._ctx_cache[1]
+        bc, tk, cd = ctx.shape
+        c16 = ctx.detach().to(device=self.device, dtype=F16).contiguous()
+        ldv = (tk + 7) & ~7
+        kvs = []
+        for st in self._all_st():
+            for blk in st["blocks"]:
+                c = st["inner"]
+                k = torch.empty((bc, tk, c), dtype=F16, device=self.device)
+                vt = torch.zeros((bc, c, ldv), dtype=F16, device=self.device)
+                ops.igemm(c16, blk["kv2_w"], 2 * c, batch=bc, hin=1, win=tk, hout=1, wout=tk, c0=cd, out=k, ld_out=c,
+                          out_t=vt, n_tr_begin=c, ld_t=ldv, ws=self._ws())
+                kvs.append((k, vt, bc, tk, ldv))
+        self._ctx_cache = (key, kvs, ctx)
+        return kvs
+
+    def _all_st(self):
+        for blk in self.input_blocks + [self.middle_block] + self.output_blocks:
+            for layer in blk:
+                if layer["kind"] == "st":
+                    yield layer
+
+    def hint_features(self, hint):
+        """input_hint_block (cldm.py:599-615): 8 convs with SiLU between; t-independent, cached per hint tensor.
+        hint: NCHW fp32 [B,3,8h,8w] in [0,1].  Returns a persistent Act [B, h*w, model_channels]."""
+        key = (hint.data_ptr(), hint._version, tuple(hint.shape))
+        if self._hint_cache is not None and self._hint_cache[0] == key:
+            return self._hint_cache[1]
+        b, c, hh, ww = hint.shape
+        hint = hint.detach().to(device=self.device, dtype=F32).contiguous()
+        x = torch.empty((b, hh * ww, 8), dtype=F16, device=self.device)
+        ops.nchw_to_nhwc_f16(hint, x, b, c, hh * ww, 8)
+        a = Act(x, b, hh, ww, 8)
+        for i, hc in enumerate(self.hint):
+            last = i == len(self.hint) - 1
+            ho, wo = ((a.h + 1) // 2, (a.w + 1) // 2) if hc["stride"] == 2 else (a.h, a.w)
+            out = torch.empty((b, ho * wo, hc["cout"]), dtype=F16, device=self.device)
+            a = self.conv(a, hc["w"], hc["cout"], k=3, stride=hc["stride"], bias=hc["b"],
+                          act=MD_ACT_NONE if last else MD_ACT_SILU, out=out)
+        self._hint_cache = (key, a, hint)
+        return a
+
+    # ------------------------------------------------------------------ blocks
+    def resblock(self, r, x, emb, x1=None):
+        h = self.gn(x, r["gn1"], x1=x1, silu=True)
+        h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total)
+        h = self.gn(h, r["gn2"], silu=True)
+        if "skip_w" in r:
+            skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"])
+        else:
+            assert x1 is None
+            skip = x
+        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip)
+
+    def attention(self, q, ld_q, k0, ld_k0, vt0, ld_vt0, n0, b, nq, heads, dh, *, k0_bs, vt0_bs, seg1=None, n1_batches=0):
+        c = heads * dh
+        out = self.arena.alloc((b, nq, c), F16)
+        kw = {}
+        if seg1 is not None:
+            k1, ld_k1, vt1, ld_vt1, n1, k1_bs, vt1_bs = seg1
+            kw = dict(k1=k1, vt1=vt1, n1=n1, ld_k1=ld_k1, ld_vt1=ld_vt1, k1_bs=k1_bs, vt1_bs=vt1_bs, n1_batches=n1_batches)
+        ops.attention(q, k0, vt0, out, batch=b, heads=heads, nq=nq, d=dh, n0=n0, ld_q=ld_q, ld_k0=ld_k0, ld_vt0=ld_vt0,
+                      ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, **kw)
+        return out
+
+    def transformer(self, st, x, ctx_kv, ctx_idx, mode, banks, bank_idx, nread):
+        """SpatialTransformer (attention.py:366-385) with the bank write / read of BasicTransformerBlock (:278-320).
+        mode: 'write' (appearance), 'read' (UNet: samples [0, nread) attend to the bank) or None (plain)."""
+        b, n, c, heads, dh = x.b, x.hw, st["inner"], st["heads"], st["dh"]
+        a = self.arena
+        xn = self.gn(x, st["gn"], eps=1e-6, silu=False)
+        t = self.conv(xn, st["pin_w"], c, k=1, bias=st["pin_b"])
+        ldv = (n + 7) & ~7
+        for blk in st["blocks"]:
+            if mode == "write":
+                dst = None if self._bank_out is None else self._bank_out[len(banks)].t
+                n1 = self.ln(t, blk["ln1"], out=dst)
+                banks.append(n1)                                                   # attention.py:287-292
+                if len(banks) == self._write_stop_at:
+                    return None  # last bank entry written: the appearance net has no other output (cldm.py:497)
+            else:
+                n1 = self.ln(t, blk["ln1"])
+            # fused q|k projection (token-major) + V^T
+            qk = a.alloc((b, n, 2 * c), F16)
+            vt = a.alloc((b, c, ldv), F16, zero=(ldv != n))
+            tok = Act(n1.t, b, 1, n, c)
+            ops.igemm(tok.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
+                      out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws())
+            seg1, n1b = None, 0
+            if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
+                bank = banks[bank_idx]                                             # attention.py:303-311
+                bb, nb = bank.b, bank.hw
+                ldvb = (nb + 7) & ~7
+                kr = a.alloc((bb, nb, c), F16)
+                vtr = a.alloc((bb, c, ldvb), F16, zero=(ldvb != nb))
+                ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=kr,
+                          ld_out=c, out_t=vtr, n_tr_begin=c, ld_t=ldvb, ws=self._ws())
+                if bb == 1:
+                    seg1 = (kr, c, vtr, ldvb, nb, 0, 0)
+                else:
+                    assert bb >= nread, "bank batch must be 1 (shared) or cover the read samples"
+                    seg1 = (kr, c, vtr, ldvb, nb, nb * c, c * ldvb)
+                n1b = nread
+            att = self.attention(qk, 2 * c, qk[:, :, c:], 2 * c, vt, ldv, n, b, n, heads, dh, k0_bs=n * 2 * c,
+                                 vt0_bs=c * ldv, seg1=seg1, n1_batches=n1b)
+            t = self.conv(Act(att, b, 1, n, c), blk["o1_w"], c, k=1, bias=blk["o1_b"], res=Act(t.t, b, 1, n, c))
+            # cross attention to the text context (attention.py:318)
+            n2 = self.ln(t, blk["ln2"])
+            q2 = self.conv(Act(n2.t, b, 1, n, c), blk["q2_w"], c, k=1)
+            kc, vtc, bc, tk, ldvc = ctx_kv[ctx_idx[0]]
+            ctx_idx[0] += 1
+            assert bc == 1 or bc == b, "context batch must be 1 or match the sample batch"
+            att2 = self.attention(q2.t, c, kc, c, vtc, ldvc, tk, b, n, heads, dh, k0_bs=(0 if bc == 1 else tk * c),
+                                  vt0_bs=(0 if bc == 1 else c * ldvc))
+            t = self.conv(Act(att2, b, 1, n, c), blk["o2_w"], c, k=1, bias=blk["o2_b"], res=Act(t.t, b, 1, n, c))
+            # GEGLU feed-forward (attention.py:50-77, 319)
+            n3 = self.ln(t, blk["ln3"])
+            ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
+            t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c))
+        t = Act(t.t, b, x.h, x.w, c)
+        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x)
+
+    def run_block(self, layers, h, emb, ctx_kv, ctx_idx, mode, banks, bank_idx, nread, x1=None):
+        """TimestepEmbedSequential.forward (openaimodel.py:79-108)."""
+        for layer in layers:
+            kind = layer["kind"]
+            if kind == "res":
+                h = self.resblock(layer, h, emb, x1=x1)
+                x1 = None
+            elif kind == "st":
+                h = self.transformer(layer, h, ctx_kv, ctx_idx, mode, banks, bank_idx[0], nread)
+                if h is None:
+                    return None
+                if mode == "read":
+                    bank_idx[0] += 1                                               # openaimodel.py:92-93
+            elif kind == "down":
+                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"])
+            elif kind == "up":
+                h = self.conv(h, layer["w"], layer["c"], k=3, ups=1, bias=layer["b"])
+            elif kind == "stem":
+                h = self.conv(h, layer["w"], layer["cout"], k=3, bias=layer["b"])
+            else:
+                raise NotImplementedError(kind)
+        assert x1 is None
+        return h
+
+    def stem_input(self, x):
+        """NCHW fp32 latent [B,4,H,W] (or a list of them, concatenated along the batch) -> NHWC fp16 padded to 8
+        channels."""
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        _, c, h, w = xs[0].shape
+        b = sum(int(xi.shape[0]) for xi in xs)
+        t = self.arena.alloc((b, h * w, 8), F16)
+        off = 0
+        for xi in xs:
+            ops.nchw_to_nhwc_f16(xi, t[off:], int(xi.shape[0]), c, h * w, 8)
+            off += int(xi.shape[0])
+        return Act(t, b, h, w, 8)
+
+    # ------------------------------------------------------------------ the three networks
+    def appearance(self, x, t_dev, ctx_kv, bank_out=None):
+        """ControlNetReferenceOnly.forward 'write' (cldm.py:469-497): returns the bank, 16 Acts [B, N_i, C_i]
+        (written straight into ``bank_out`` when given, e.g. a row of the per-step bank table)."""
+        assert self.kind == "appearance"
+        self._bank_out = bank_out
+        emb = self.time_embedding(t_dev, x.shape[0])
+        banks, hs, ctx_idx = [], [], [0]
+        h = self.stem_input(x)
+        for blk in self.input_blocks:
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0)
+            hs.append(h)
+        h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0)
+        for blk in self.output_blocks:
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0, x1=hs.pop())
+            if h is None:
+                break  # nothing after the last bank write influences any output (the net returns [])
+        return banks
+
+    def pose(self, x, hint_feat, t_dev, ctx_kv):
+        """ControlNet.forward (cldm.py:736-757): 13 zero-conv outputs as Acts."""
+        assert self.kind == "pose"
+        emb = self.time_embedding(t_dev, x.shape[0])
+        outs, ctx_idx = [], [0]
+        h = self.stem_input(x)
+        for i, blk in enumerate(self.input_blocks):
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
+            if i == 0:
+                n = h.b * h.hw * h.c
+                ops.add_f16(h.t, hint_feat.t, h.t, n, hint_feat.b * hint_feat.hw * hint_feat.c)  # h += guided_hint
+            z = self.zero_convs[i]
+            outs.append(self.conv(h, z["w"], h.c, k=1, bias=z["b"]))
+        h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
+        outs.append(self.conv(h, self.mid_out["w"], h.c, k=1, bias=self.mid_out["b"]))
+        return outs
+
+    def unet(self, x, t_dev, ctx_kv, banks=None, pose=None, nread=0, only_mid_control=False, eps_out=None):
+        """ControlledUnetModelAttnPose.forward (cldm.py:59-112) on a batch whose first ``nread`` samples take the
+        'read' branch (:86-107: bank attention + pose residuals) and whose remaining samples take the 'uc' branch
+        (:70-84: plain UNet) -- both branches share every weight, so they run as one batch.
+        Returns eps as NHWC fp32 [B, H*W, 4]."""
+        assert self.kind == "unet"
+        b = sum(int(xi.shape[0]) for xi in x) if isinstance(x, (list, tuple)) else x.shape[0]
+        emb = self.time_embedding(t_dev, b)
+        use_bank_in = nread > 0 and banks is not None and len(banks) > 0
+        use_bank = use_bank_in and not only_mid_control                            # cldm.py:98-106
+        mode = "read"
+        hs, ctx_idx, bank_idx = [], [0], [0]
+        pose = None if pose is None else list(pose)
+        h = self.stem_input(x)
+        for blk in self.input_blocks:
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
+            hs.append(h)
+        h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
+        if nread > 0 and pose is not None:
+            pr = pose.pop()                                                        # cldm.py:93-95
+            hh = h.head(nread)
+            ops.add_f16(hh.t, pr.t, hh.t, nread * h.hw * h.c, pr.b * pr.hw * pr.c)
+        for blk in self.output_blocks:
+            skip = hs.pop()
+            if nread > 0 and pose is not None and not only_mid_control and use_bank:
+                pr = pose.pop()                                                    # cldm.py:102-104
+                sh = skip.head(nread)
+                ops.add_f16(sh.t, pr.t, sh.t, nread * skip.hw * skip.c, pr.b * pr.hw * pr.c)
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank else None, banks, bank_idx, nread, x1=skip)
+        hn = self.gn(h, self.head_gn, silu=True)
+        if eps_out is None:
+            eps_out = self.arena.alloc((b, h.hw, self.cfg.out_channels), F32)
+        self.conv(hn, self.head_w, self.cfg.out_channels, k=3, bias=self.head_b, out_f32=True, out=eps_out)
+        return eps_out
+
+    # ------------------------------------------------------------------ public-module entry points (nets.py)
+    def _t_dev(self, timesteps, b):
+        t = timesteps.detach().to(device=self.device, dtype=F32).reshape(-1)
+        if t.numel() == 1 and b > 1:
+            t = t.expand(b)
+        return t.contiguous()
+
+    def unet_forward(self, x, timesteps, context, control, pose_control, only_mid_control, attention_mode, uc):
+        self.arena.reset()
+        x = x.detach().to(device=self.device, dtype=F32).contiguous()
+        b, _, hh, ww = x.shape
+        ctx_kv = self.context_kv(context)
+        banks = None
+        if not uc and control:
+            banks = [_as_bank(e, self.device) for e in control]
+        pose = None
+        if not uc and pose_control is not None:
+            pose = [_as_act(p, self.device) for p in pose_control]
+            del pose_control[:]  # the reference consumes the list with pop() (cldm.py:95,104)
+        eps = self.unet(x, self._t_dev(timesteps, b), ctx_kv, banks=banks, pose=pose, nread=0 if uc else b,
+                        only_mid_control=only_mid_control)
+        out = torch.empty((b, self.cfg.out_channels, hh, ww), dtype=F32, device=self.device)
+        ops.nhwc_to_nchw_f32(eps, out, b, self.cfg.out_channels, hh * ww, self.cfg.out_channels)
+        return out
+
+    def appearance_forward(self, x, timesteps, context, attention_bank, attention_mode, uc):
+        if attention_mode != "write":
+            raise NotImplementedError("the appearance net is only ever run in 'write' mode (cldm.py:1110)")
+        self.arena.reset()
+        x = x.detach().to(device=self.device, dtype=F32).contiguous()
+        banks = self.appearance(x, self._t_dev(timesteps, x.shape[0]), self.context_kv(context))
+        for bk in banks:
+            attention_bank.append([bk.t.clone()])                                  # [B, N, C] fp16
+        return []
+
+    def pose_forward(self, x, hint, timesteps, context):
+        self.arena.reset()
+        x = x.detach().to(device=self.device, dtype=F32).contiguous()
+        outs = self.pose(x, self.hint_features(hint), self._t_dev(timesteps, x.shape[0]), self.context_kv(context))
+        res = []
+        for o in outs:
+            t = torch.empty((o.b, o.c, o.h, o.w), dtype=F32, device=self.device)
+            ops.nhwc_to_nchw_f32(o.t, t, o.b, o.c, o.hw, o.c)
+            res.append(t)
+        return res
+
+
+def _as_bank(entry, device):
+    """bank entry from the public API: [tensor [B,N,C]] (list, as in the reference) or a bare tensor / Act."""
+    if isinstance(entry, Act):
+        return entry
+    t = entry[0] if isinstance(entry, (list, tuple)) else entry
+    t = t.detach().to(device=device, dtype=F16).contiguous()
+    b, n, c = t.shape
+    return Act(t, b, 1, n, c)
+
+
+def _as_act(p, device):
+    """pose residual from the public API: NCHW tensor -> NHWC fp16 Act (layout change only)."""
+    if isinstance(p, Act):
+        return p
+    b, c, h, w = p.shape
+    t = p.detach().to(device=device, dtype=F16).permute(0, 2, 3, 1).reshape(b, h * w, c).contiguous()
+    return Act(t, b, h, w, c)

@@ -1,0 +1,151 @@
+"""Python-side wrappers of the C ABI (include/magicdance_hip.h): torch tensors are used only as device-memory
+handles (``data_ptr()``) and the launch goes on torch's current HIP stream.  No arithmetic happens here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import IgemmParams, AttentionParams, GroupNormParams, MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU  # noqa: F401
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
+          bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0):
+    """See md_igemm.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
+    lib = _lib.load()
+    p = IgemmParams()
+    p.a0, p.a1, p.c0, p.c1 = _p(a0), _p(a1), c0, c1
+    p.batch, p.hin, p.win, p.hout, p.wout = batch, hin, win, hout, wout
+    p.ksize, p.stride, p.ups = ksize, stride, ups
+    p.w, p.n = _p(w), n
+    p.bias, p.bias_batch_stride = _p(bias), bias_batch_stride
+    p.res, p.ld_res = _p(res), ld_res
+    p.act = act
+    p.out, p.ld_out, p.out_f32 = _p(out), (ld_out if ld_out is not None else n), int(out_f32)
+    p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
+    p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
+    p.force_cfg, p.force_splitk = force_cfg, force_splitk
+    _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
+    return out
+
+
+def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None):
+    lib = _lib.load()
+    p = AttentionParams()
+    p.q, p.q_batch_stride, p.ld_q = _p(q), q_bs, ld_q
+    p.k0, p.k0_batch_stride, p.ld_k0 = _p(k0), k0_bs, ld_k0
+    p.vt0, p.vt0_batch_stride, p.ld_vt0, p.n0 = _p(vt0), vt0_bs, ld_vt0, n0
+    p.k1, p.k1_batch_stride, p.ld_k1 = _p(k1), k1_bs, ld_k1
+    p.vt1, p.vt1_batch_stride, p.ld_vt1, p.n1 = _p(vt1), vt1_bs, ld_vt1, n1
+    p.n1_batches = n1_batches
+    p.out, p.out_batch_stride, p.ld_out = _p(out), out_bs, ld_out
+    p.batch, p.heads, p.nq, p.d = batch, heads, nq, d
+    p.scale = float(d) ** -0.5 if scale is None else scale
+    _lib.check(lib.md_attention(C.byref(p), stream_ptr()), "md_attention")
+    return out
+
+
+def groupnorm_ws_bytes(batch, hw, groups=32):
+    return int(_lib.load().md_groupnorm_workspace_bytes(batch, hw, groups))
+
+
+def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False):
+    lib = _lib.load()
+    p = GroupNormParams()
+    p.x0, p.x1, p.c0, p.c1 = _p(x0), _p(x1), c0, c1
+    p.batch, p.hw, p.groups, p.eps = batch, hw, groups, eps
+    p.gamma, p.beta, p.silu, p.out = _p(gamma), _p(beta), int(silu), _p(out)
+    p.ws, p.ws_bytes = _p(ws), ws.numel() * ws.element_size()
+    _lib.check(lib.md_groupnorm(C.byref(p), stream_ptr()), "md_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, out, rows, c, eps=1e-5):
+    _lib.check(_lib.load().md_layernorm(_p(x), _p(gamma), _p(beta), _p(out), rows, c, eps, stream_ptr()), "md_layernorm")
+    return out
+
+
+def nchw_to_nhwc_f16(x, out, batch, c, hw, cpad):
+    _lib.check(_lib.load().md_nchw_to_nhwc_f16(_p(x), _p(out), batch, c, hw, cpad, stream_ptr()), "md_nchw_to_nhwc_f16")
+    return out
+
+
+def nhwc_to_nchw_f32(x, out, batch, c, hw, ld):
+    is_f32 = 1 if x.dtype == torch.float32 else 0
+    _lib.check(_lib.load().md_nhwc_to_nchw_f32(_p(x), is_f32, _p(out), batch, c, hw, ld, stream_ptr()),
+               "md_nhwc_to_nchw_f32")
+    return out
+
+
+def add_f16(a, b, out, n, b_period=None):
+    _lib.check(_lib.load().md_add_f16(_p(a), _p(b), _p(out), n, n if b_period is None else b_period, stream_ptr()),
+               "md_add_f16")
+    return out
+
+
+def timestep_embedding(t, out, nt, dim, max_period=10000.0):
+    _lib.check(_lib.load().md_timestep_embedding(_p(t), _p(out), nt, dim, max_period, stream_ptr()),
+               "md_timestep_embedding")
+    return out
+
+
+def gemv_f32(x, w, bias, y, rows, k, n, act_in=False):
+    _lib.check(_lib.load().md_gemv_f32(_p(x), _p(w), _p(bias), _p(y), rows, k, n, int(act_in), stream_ptr()), "md_gemv_f32")
+    return y
+
+
+def select_row_f32(table, counter, row_offset, dst, width):
+    _lib.check(_lib.load().md_select_row_f32(_p(table), _p(counter), row_offset, _p(dst), width, stream_ptr()),
+               "md_select_row_f32")
+    return dst
+
+
+def counter_add(counter, delta):
+    _lib.check(_lib.load().md_counter_add(_p(counter), delta, stream_ptr()), "md_counter_add")
+
+
+def ddim_update(eps_c, eps_u, ld_eps, x, noise, coef, x_prev, pred_x0, eps_out, batch, c, hw):
+    _lib.check(_lib.load().md_ddim_update(_p(eps_c), _p(eps_u), ld_eps, _p(x), _p(noise), _p(coef), _p(x_prev),
+                                          _p(pred_x0), _p(eps_out), batch, c, hw, stream_ptr()), "md_ddim_update")
+    return x_prev
+
+
+class Graph:
+    """A captured launch sequence (hipGraphExec)."""
+
+    def __init__(self):
+        self.handle = C.c_void_p(0)
+
+    def begin(self):
+        _lib.check(_lib.load().md_graph_begin(stream_ptr()), "md_graph_begin")
+
+    def end(self):
+        _lib.check(_lib.load().md_graph_end(stream_ptr(), C.byref(self.handle)), "md_graph_end")
+
+    def launch(self):
+        _lib.check(_lib.load().md_graph_launch(self.handle, stream_ptr()), "md_graph_launch")
+
+    def destroy(self):
+        if self.handle:
+            _lib.load().md_graph_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+
+def prof_enable(on):
+    _lib.load().md_prof_enable(int(on))
+
+
+def prof_collect():
+    n = len(_lib.FAMILIES)
+    ms, la, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    _lib.check(_lib.load().md_prof_collect(ms, la, fl, by), "md_prof_collect")
+    return {f: dict(ms=ms[i], launches=la[i], flops=fl[i], bytes=by[i]) for i, f in enumerate(_lib.FAMILIES)}

@@ -58,3 +58,24 @@ def summarize(t):
 def head_slice(t, n=4):
     t = t.detach().float()
     return (t[:, :n] if t.dim() == 3 else t[:, :, :1, :n]).contiguous().cpu().numpy()
+
+
+def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64):
+    """The product model (magicdance_amd.cldm.ControlLDMReferenceOnlyPose) built from the shipped YAML with the
+    golden case's geometry, loaded with the seeded synthetic weights."""
+    import magicdance_amd as M
+    cfg = M.cldm.load_config(M.DEFAULT_CONFIG)["model"]
+    for blk in ("appearance_control_stage_config", "pose_control_stage_config", "unet_config"):
+        cfg["params"][blk]["params"].update(model_channels=model_channels, num_heads=num_heads)
+    cfg["params"]["first_stage_config"] = "__is_first_stage__"
+    cfg["params"]["cond_stage_config"] = "__is_unconditional__"
+    cfg["params"]["image_size"] = image_size
+    with torch.device("meta"):
+        model = M.instantiate_from_config(cfg)
+    model = model.to_empty(device=device)
+    model.register_schedule(timesteps=1000, linear_start=cfg["params"]["linear_start"], linear_end=cfg["params"]["linear_end"])
+    model.logvar = torch.zeros(1000)
+    sd = synth_weights(model_channels, num_heads, seed=seed, device="cpu")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(not k.startswith(("model.", "appearance", "pose")) for k in missing), (missing[:5], unexpected[:5])
+    return model.to(device).eval()

@@ -1,0 +1,206 @@
+"""TEST INFRASTRUCTURE ONLY: torch-CPU emulation of the C ABI (include/magicdance_hip.h) with the same pointer /
+leading-dimension semantics, so that the HOST logic of the product (weight packing, NHWC layouts, fused-QKV and
+V^T stores, GEGLU interleave, bank read/write plumbing, arena reuse, sampler control flow) can be checked against
+the reference goldens in the CPU test tier.  It is installed by monkeypatching ``magicdance_amd.ops`` inside a test;
+nothing in the product imports it, and it is never what a GPU test or the bench measures."""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _mem(t, size, stride):
+    """pointer semantics: ``t``'s first element is the base address; view memory from there."""
+    return t.as_strided(size, stride, t.storage_offset())
+
+
+def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
+          bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0):
+    cin = c0 + c1
+    xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
+    if a1 is not None:
+        xs.append(_mem(a1, (batch, hin, win, c1), (hin * win * c1, win * c1, c1, 1)).float())
+    x = torch.cat(xs, -1).permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    kk = ksize * ksize * cin
+    wt = _mem(w, (n, ksize, ksize, cin), (kk, ksize * cin, cin, 1)).float().permute(0, 3, 1, 2)
+    y = F.conv2d(x, wt, stride=stride, padding=ksize // 2)
+    assert y.shape[2] == hout and y.shape[3] == wout, (y.shape, hout, wout)
+    tokens = hout * wout
+    y = y.permute(0, 2, 3, 1).reshape(batch, tokens, n)
+    if bias is not None:
+        if bias_batch_stride:
+            y = y + _mem(bias, (batch, 1, n), (bias_batch_stride, 0, 1))
+        else:
+            y = y + _mem(bias, (n,), (1,))
+    ld_out = n if ld_out is None else ld_out
+    if act == 2:  # GEGLU on 16-row interleaved packing
+        y = y.reshape(batch, tokens, n // 32, 2, 16)
+        y = (y[..., 0, :] * F.gelu(y[..., 1, :])).reshape(batch, tokens, n // 2)
+        _mem(out, (batch, tokens, n // 2), (tokens * ld_out, ld_out, 1)).copy_(y)
+        return out
+    if act == 1:
+        y = F.silu(y)
+    ntr0 = n if n_tr_begin is None else n_tr_begin
+    if ntr0 < n:
+        ntr = n - ntr0
+        _mem(out_t, (batch, ntr, tokens), (ntr * ld_t, ld_t, 1)).copy_(y[..., ntr0:].transpose(1, 2))
+        y = y[..., :ntr0]
+    if res is not None:
+        y = y + _mem(res, (batch, tokens, ntr0), (tokens * ld_res, ld_res, 1)).float()
+    _mem(out, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1)).copy_(y)
+    return out
+
+
+def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None):
+    scale = d ** -0.5 if scale is None else scale
+    qq = _mem(q, (batch, heads, nq, d), (q_bs, d, ld_q, 1)).float()
+    kk = _mem(k0, (batch, heads, n0, d), (k0_bs, d, ld_k0, 1)).float()
+    vv = _mem(vt0, (batch, heads, n0, d), (vt0_bs, d * ld_vt0, 1, ld_vt0)).float()
+    o = _mem(out, (batch, heads, nq, d), (out_bs, d, ld_out, 1))
+    for b in range(batch):
+        kb, vb = kk[b], vv[b]
+        if k1 is not None and b < n1_batches:
+            k1b = _mem(k1, (batch, heads, n1, d), (k1_bs, d, ld_k1, 1)).float()[b]
+            v1b = _mem(vt1, (batch, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1)).float()[b]
+            kb, vb = torch.cat([kb, k1b], 1), torch.cat([vb, v1b], 1)
+        s = torch.einsum("hid,hjd->hij", qq[b], kb) * scale
+        o[b].copy_(torch.einsum("hij,hjd->hid", s.softmax(-1), vb))
+    return out
+
+
+def groupnorm_ws_bytes(batch, hw, groups=32):
+    return 1024
+
+
+def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False):
+    xs = [_mem(x0, (batch, hw, c0), (hw * c0, c0, 1)).float()]
+    if x1 is not None:
+        xs.append(_mem(x1, (batch, hw, c1), (hw * c1, c1, 1)).float())
+    x = torch.cat(xs, -1).transpose(1, 2)  # [B, C, HW]
+    y = F.group_norm(x, groups, gamma.float(), beta.float(), eps=eps)
+    if silu:
+        y = F.silu(y)
+    c = c0 + c1
+    _mem(out, (batch, hw, c), (hw * c, c, 1)).copy_(y.transpose(1, 2))
+    return out
+
+
+def layernorm(x, gamma, beta, out, rows, c, eps=1e-5):
+    y = F.layer_norm(_mem(x, (rows, c), (c, 1)).float(), (c,), gamma, beta, eps)
+    _mem(out, (rows, c), (c, 1)).copy_(y)
+    return out
+
+
+def nchw_to_nhwc_f16(x, out, batch, c, hw, cpad):
+    o = _mem(out, (batch, hw, cpad), (hw * cpad, cpad, 1))
+    o.zero_()
+    o[..., :c].copy_(_mem(x, (batch, c, hw), (c * hw, hw, 1)).transpose(1, 2))
+    return out
+
+
+def nhwc_to_nchw_f32(x, out, batch, c, hw, ld):
+    _mem(out, (batch, c, hw), (c * hw, hw, 1)).copy_(_mem(x, (batch, hw, c), (hw * ld, ld, 1)).transpose(1, 2))
+    return out
+
+
+def add_f16(a, b, out, n, b_period=None):
+    b_period = n if b_period is None else b_period
+    av = _mem(a, (n // b_period, b_period), (b_period, 1)).float()
+    r = av + _mem(b, (1, b_period), (0, 1)).float()
+    _mem(out, (n // b_period, b_period), (b_period, 1)).copy_(r)
+    return out
+
+
+def timestep_embedding(t, out, nt, dim, max_period=10000.0):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=F32) / half)
+    args = _mem(t, (nt,), (1,))[:, None].float() * freqs[None]
+    _mem(out, (nt, dim), (dim, 1)).copy_(torch.cat([torch.cos(args), torch.sin(args)], -1))
+    return out
+
+
+def gemv_f32(x, w, bias, y, rows, k, n, act_in=False):
+    xv = _mem(x, (rows, k), (k, 1)).float()
+    if act_in:
+        xv = F.silu(xv)
+    r = xv @ _mem(w, (n, k), (k, 1)).float().t()
+    if bias is not None:
+        r = r + _mem(bias, (n,), (1,))
+    _mem(y, (rows, n), (n, 1)).copy_(r)
+    return y
+
+
+def select_row_f32(table, counter, row_offset, dst, width):
+    row = (int(counter[0]) if counter is not None else 0) + row_offset
+    _mem(dst, (width,), (1,)).copy_(_mem(table, (row + 1, width), (width, 1))[row])
+    return dst
+
+
+def counter_add(counter, delta):
+    counter += delta
+
+
+def ddim_update(eps_c, eps_u, ld_eps, x, noise, coef, x_prev, pred_x0, eps_out, batch, c, hw):
+    a_t, a_prev, sigma, s1m, scale = [float(v) for v in coef]
+    e = _mem(eps_c, (batch, hw, c), (hw * ld_eps, ld_eps, 1)).transpose(1, 2)
+    if eps_u is not None:
+        eu = _mem(eps_u, (batch, hw, c), (hw * ld_eps, ld_eps, 1)).transpose(1, 2)
+        e = eu + scale * (e - eu)
+    xv = _mem(x, (batch, c, hw), (c * hw, hw, 1)).clone()
+    px0 = (xv - s1m * e) / math.sqrt(a_t)
+    xp = math.sqrt(a_prev) * px0 + math.sqrt(1.0 - a_prev - sigma ** 2) * e
+    if noise is not None:
+        xp = xp + sigma * _mem(noise, (batch, c, hw), (c * hw, hw, 1))
+    _mem(x_prev, (batch, c, hw), (c * hw, hw, 1)).copy_(xp)
+    if pred_x0 is not None:
+        _mem(pred_x0, (batch, c, hw), (c * hw, hw, 1)).copy_(px0)
+    if eps_out is not None:
+        _mem(eps_out, (batch, c, hw), (c * hw, hw, 1)).copy_(e)
+    return x_prev
+
+
+class Graph:
+    def begin(self):
+        self.fn = None
+
+    def end(self):
+        pass
+
+    def launch(self):
+        raise RuntimeError("the emulator does not capture graphs: run FusedStepRunner with use_graph=False")
+
+    def destroy(self):
+        pass
+
+
+class _Stream:
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, other):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def install(monkeypatch):
+    """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
+    from magicdance_amd import ops, engine
+    for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "layernorm", "nchw_to_nhwc_f16",
+                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "counter_add",
+                 "ddim_update", "Graph"):
+        monkeypatch.setattr(ops, name, globals()[name])
+    monkeypatch.setattr(engine, "_require_gpu", lambda device: None)
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    engine._ARENAS.clear()
+    engine._WS.clear()

@@ -1,0 +1,317 @@
+"""GPU parity of each C-ABI kernel against a plain PyTorch fp32 reference of the same op (inputs rounded to the
+fp16 values the kernel sees, so the only differences are accumulation order and the fp16 rounding of the output).
+Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = torch.float16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from magicdance_amd import _lib
+    _lib.load()  # fails loudly if the HIP extension is missing
+    return torch.device("cuda:0")
+
+
+def _gen(seed):
+    return torch.Generator(device="cpu").manual_seed(seed)
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    return (torch.randn(shape, generator=_gen(seed)) * scale).to(dev)
+
+
+def _nhwc16(x):  # NCHW fp32 -> NHWC fp16 [B, HW, C]
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b, h * w, c).to(F16).contiguous()
+
+
+def _nchw32(t, b, h, w):  # NHWC [B, HW, C] -> NCHW fp32
+    return t.float().reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def _err(a, b):
+    return float((a.float() - b.float()).abs().max())
+
+
+CONV_CASES = [
+    # name, B, Cin(s), H, W, Cout, k, stride, ups
+    ("c3_s1", 2, (64,), 16, 16, 96, 3, 1, 0),
+    ("c3_s2", 2, (64,), 16, 16, 64, 3, 2, 0),
+    ("c3_up", 1, (64,), 8, 8, 64, 3, 1, 1),
+    ("c3_cat", 2, (64, 128), 8, 8, 128, 3, 1, 0),
+    ("c1_cat", 1, (128, 64), 16, 16, 320, 1, 1, 0),
+    ("c3_big", 1, (320,), 32, 32, 320, 3, 1, 0),
+    ("c3_smallc", 1, (8,), 24, 24, 16, 3, 1, 0),
+    ("c3_c96", 1, (96,), 12, 12, 96, 3, 2, 0),
+    ("c3_head", 1, (320,), 16, 16, 4, 3, 1, 0),
+    ("c3_odd", 1, (64,), 7, 9, 64, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+def test_igemm_conv(dev, case, cfg):
+    from magicdance_amd import ops, engine
+    name, b, cins, h, w, cout, k, stride, ups = case
+    xs = [_rand((b, c, h, w), 10 + i, dev) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    wt = _rand((cout, cin, k, k), 20, dev, scale=(cin * k * k) ** -0.5)
+    bias = _rand((cout,), 21, dev, 0.1)
+    x16 = [_nhwc16(x) for x in xs]
+    w16 = engine.pack_conv(wt, dev)
+    xin = torch.cat([x.half().float() for x in xs], 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wt.half().float(), bias, stride=stride, padding=k // 2)
+    ho, wo = ref.shape[2], ref.shape[3]
+    out = torch.empty((b, ho * wo, cout), dtype=F16, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride, ups=ups,
+              a1=x16[1] if len(cins) > 1 else None, c1=cins[1] if len(cins) > 1 else 0, bias=bias, out=out, ws=ws,
+              force_cfg=cfg)
+    got = _nchw32(out, b, ho, wo)
+    # fp32 accumulate, one fp16 rounding of O(1) outputs: 2e-3 abs covers |y| up to ~4
+    assert _err(got, ref) <= 4e-3 * max(1.0, float(ref.abs().max())), name
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 8])
+def test_igemm_splitk_epilogues(dev, splitk):
+    """split-K slabs + reduce kernel, with per-batch bias (time-embedding add), SiLU and residual."""
+    from magicdance_amd import ops, engine
+    b, cin, h, w, cout = 2, 320, 8, 8, 128
+    x = _rand((b, cin, h, w), 1, dev)
+    wt = _rand((cout, cin, 3, 3), 2, dev, (cin * 9) ** -0.5)
+    bias_b = _rand((b, 256), 3, dev, 0.5)      # per-sample bias rows, stride 256, offset 64
+    res = _rand((b, cout, h, w), 4, dev)
+    ref = F.conv2d(x.half().float(), wt.half().float(), None, padding=1) + bias_b[:, 64:64 + cout, None, None]
+    ref = F.silu(ref) + res.half().float()
+    out = torch.empty((b, h * w, cout), dtype=F16, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ops.igemm(_nhwc16(x), engine.pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=3,
+              bias=bias_b[:, 64:], bias_batch_stride=256, res=_nhwc16(res), ld_res=cout, act=ops.MD_ACT_SILU, out=out,
+              ws=ws, force_splitk=splitk)
+    assert _err(_nchw32(out, b, h, w), ref) <= 6e-3
+
+
+def test_igemm_linear_f32_transposed_geglu(dev):
+    from magicdance_amd import ops, engine
+    b, n, c = 2, 80, 64  # tokens not a multiple of the tile
+    x = _rand((b, n, c), 1, dev)
+    x16 = x.to(F16).contiguous()
+    xr = x16.float()
+    # (a) fused q|k token-major + V^T transposed store
+    wq = _rand((3 * c, c), 2, dev, c ** -0.5)
+    qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
+    ldv = 88
+    vt = torch.zeros((b, c, ldv), dtype=F16, device=dev)
+    ops.igemm(x16, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
+              out_t=vt, n_tr_begin=2 * c, ld_t=ldv)
+    ref = xr @ wq.half().float().t()
+    assert _err(qk, ref[..., :2 * c]) <= 4e-3
+    assert _err(vt[:, :, :n], ref[..., 2 * c:].transpose(1, 2)) <= 4e-3
+    assert float(vt[:, :, n:].abs().max()) == 0.0
+    # (b) fp32 output
+    o32 = torch.empty((b, n, 3 * c), dtype=F32, device=dev)
+    ops.igemm(x16, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=o32, out_f32=True)
+    assert _err(o32, ref) <= 2e-4
+    # (c) GEGLU: x W^T + b -> a * gelu(gate)
+    w1, b1 = _rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1)
+    wp, bp = engine.pack_geglu(w1, b1, dev)
+    og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
+    ops.igemm(x16, wp, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og,
+              ld_out=4 * c)
+    hr = xr @ w1.half().float().t() + b1
+    a, g = hr.chunk(2, dim=-1)
+    assert _err(og, a * F.gelu(g)) <= 6e-3
+
+
+ATTN_CASES = [
+    # name, B, H, Nq, N0, N1, n1_batches, d, bank_shared
+    ("d40_self", 1, 8, 256, 256, 0, 0, 40, True),
+    ("d40_bank", 2, 4, 192, 192, 192, 1, 40, True),      # sample 0 reads the bank, sample 1 (uc) does not
+    ("d80_bank_per_sample", 2, 2, 128, 128, 128, 2, 80, False),
+    ("d160_bank", 1, 8, 64, 64, 64, 1, 160, True),
+    ("d40_ctx77", 2, 8, 100, 77, 0, 0, 40, True),        # cross-attention: kv tail masking, ld_vt padding
+    ("d64_tiny", 1, 2, 16, 16, 16, 1, 64, True),
+    ("d32_n4", 1, 2, 4, 4, 4, 1, 32, True),
+    ("d128", 1, 2, 64, 64, 0, 0, 128, True),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(dev, case):
+    from magicdance_amd import ops
+    name, b, heads, nq, n0, n1, n1b, d, shared = case
+    c = heads * d
+    q = _rand((b, nq, c), 1, dev).to(F16)
+    k0 = _rand((b, n0, c), 2, dev).to(F16)
+    v0 = _rand((b, n0, c), 3, dev).to(F16)
+    ld0 = (n0 + 7) // 8 * 8
+    vt0 = torch.zeros((b, c, ld0), dtype=F16, device=dev)
+    vt0[:, :, :n0] = v0.transpose(1, 2)
+    kw = {}
+    if n1:
+        bb = 1 if shared else b
+        k1 = _rand((bb, n1, c), 4, dev).to(F16)
+        v1 = _rand((bb, n1, c), 5, dev).to(F16)
+        ld1 = (n1 + 7) // 8 * 8
+        vt1 = torch.zeros((bb, c, ld1), dtype=F16, device=dev)
+        vt1[:, :, :n1] = v1.transpose(1, 2)
+        kw = dict(k1=k1, vt1=vt1, n1=n1, ld_k1=c, ld_vt1=ld1, k1_bs=0 if shared else n1 * c,
+                  vt1_bs=0 if shared else c * ld1, n1_batches=n1b)
+    out = torch.empty((b, nq, c), dtype=F16, device=dev)
+    ops.attention(q, k0, vt0, out, batch=b, heads=heads, nq=nq, d=d, n0=n0, ld_q=c, ld_k0=c, ld_vt0=ld0, ld_out=c,
+                  q_bs=nq * c, k0_bs=n0 * c, vt0_bs=c * ld0, out_bs=nq * c, **kw)
+    sp = lambda t: t.float().reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3)  # noqa: E731
+    ref = torch.empty((b, nq, c), dtype=F32, device=dev)
+    for i in range(b):
+        kk, vv = k0[i:i + 1], v0[i:i + 1]
+        if n1 and i < n1b:
+            j = 0 if shared else i
+            kk, vv = torch.cat([kk, k1[j:j + 1]], 1), torch.cat([vv, v1[j:j + 1]], 1)
+        s = torch.einsum("bhid,bhjd->bhij", sp(q[i:i + 1]), sp(kk)) * d ** -0.5
+        o = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), sp(vv))
+        ref[i] = o.permute(0, 2, 1, 3).reshape(nq, c)
+    # P is rounded to fp16 before PV and the output to fp16: 3e-3 abs on O(1) values
+    assert _err(out, ref) <= 4e-3, name
+
+
+def test_attention_spike_rescale(dev):
+    """online-softmax rescale path: one key dominates from a late tile on (running max jumps)."""
+    from magicdance_amd import ops
+    b, heads, n, d = 1, 2, 256, 40
+    c = heads * d
+    q = _rand((b, n, c), 1, dev).to(F16)
+    k = _rand((b, n, c), 2, dev).to(F16)
+    v = _rand((b, n, c), 3, dev).to(F16)
+    k[:, 200] = (q[:, 17] * 4).to(F16)  # spike against query 17 in the 4th kv tile
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty((b, n, c), dtype=F16, device=dev)
+    ops.attention(q, k, vt, out, batch=b, heads=heads, nq=n, d=d, n0=n, ld_q=c, ld_k0=c, ld_vt0=n, ld_out=c,
+                  q_bs=n * c, k0_bs=n * c, vt0_bs=c * n, out_bs=n * c)
+    sp = lambda t: t.double().reshape(b, n, heads, d).permute(0, 2, 1, 3)  # noqa: E731
+    s = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, n, c)
+    assert _err(out, ref) <= 4e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 320, 16, 16, None), (1, 64, 8, 8, None), (2, 640, 8, 8, 320), (1, 1920, 4, 4, 1280),
+                                   (1, 320, 64, 64, None)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm(dev, shape, silu):
+    from magicdance_amd import ops
+    b, c, h, w, c0 = shape
+    x = _rand((b, c, h, w), 1, dev) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * _rand((c,), 2, dev), 0.1 * _rand((c,), 3, dev)
+    eps = 1e-5 if silu else 1e-6
+    ref = F.group_norm(x.half().float(), 32, gamma, beta, eps=eps)
+    ref = F.silu(ref) if silu else ref
+    x16 = _nhwc16(x)
+    out = torch.empty((b, h * w, c), dtype=F16, device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    if c0 is None:
+        ops.groupnorm(x16, gamma, beta, out, ws, batch=b, hw=h * w, c0=c, eps=eps, silu=silu)
+    else:
+        xa, xb = x16[..., :c0].contiguous(), x16[..., c0:].contiguous()
+        ops.groupnorm(xa, gamma, beta, out, ws, batch=b, hw=h * w, c0=c0, x1=xb, c1=c - c0, eps=eps, silu=silu)
+    assert _err(_nchw32(out, b, h, w), ref) <= 4e-3
+
+
+@pytest.mark.parametrize("c", [64, 320, 640, 1280])
+def test_layernorm(dev, c):
+    from magicdance_amd import ops
+    rows = 77
+    x = _rand((rows, c), 1, dev) * 3 + 1
+    gamma, beta = 1 + 0.1 * _rand((c,), 2, dev), 0.1 * _rand((c,), 3, dev)
+    x16 = x.to(F16).contiguous()
+    out = torch.empty_like(x16)
+    ops.layernorm(x16, gamma, beta, out, rows, c)
+    assert _err(out, F.layer_norm(x16.float(), (c,), gamma, beta)) <= 4e-3
+
+
+def test_embedding_path(dev):
+    """timestep_embedding (util.py:189-209) and the GEMV chain of the time-embed MLP."""
+    from magicdance_amd import ops
+    t = torch.tensor([981.0, 1.0, 501.0], device=dev)
+    dim, half = 320, 160
+    out = torch.empty((3, dim), dtype=F32, device=dev)
+    ops.timestep_embedding(t, out, 3, dim)
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=F32) / half).to(dev)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert _err(out, ref) <= 5e-4  # fp32 argument up to ~1e3 rad: 1 ulp of the frequency moves cos by ~1e-4
+    w, b = _rand((1280, dim), 1, dev, dim ** -0.5), _rand((1280,), 2, dev, 0.1)
+    y = torch.empty((3, 1280), dtype=F32, device=dev)
+    ops.gemv_f32(ref.contiguous(), w.to(F16).contiguous(), b, y, 3, dim, 1280, act_in=True)
+    assert _err(y, F.linear(F.silu(ref), w.half().float(), b)) <= 1e-4
+    x = _rand((11, 1280), 3, dev)
+    y2 = torch.empty((11, 1280), dtype=F32, device=dev)
+    ops.gemv_f32(x, _rand((1280, 1280), 4, dev, 0.03).to(F16).contiguous(), None, y2, 11, 1280, 1280)
+    assert _err(y2, x @ _rand((1280, 1280), 4, dev, 0.03).half().float().t()) <= 2e-4
+
+
+def test_layout_add_ddim(dev):
+    from magicdance_amd import ops
+    b, c, h, w = 2, 4, 8, 8
+    x = _rand((b, c, h, w), 1, dev)
+    t = torch.empty((b, h * w, 8), dtype=F16, device=dev)
+    ops.nchw_to_nhwc_f16(x, t, b, c, h * w, 8)
+    assert _err(t[..., :4], _nhwc16(x)) == 0.0 and float(t[..., 4:].abs().max()) == 0.0
+    back = torch.empty_like(x)
+    ops.nhwc_to_nchw_f32(t, back, b, c, h * w, 8)
+    assert _err(back, x.half()) == 0.0
+    a16, b16 = _rand((2, 64, 32), 2, dev).to(F16), _rand((1, 64, 32), 3, dev).to(F16)
+    o = torch.empty_like(a16)
+    ops.add_f16(a16, b16, o, a16.numel(), b16.numel())
+    assert _err(o, (a16.float() + b16.float()).to(F16)) == 0.0
+    # fused CFG + DDIM update (ddim.py:605,617-645)
+    e_c, e_u = _rand((b, h * w, c), 4, dev), _rand((b, h * w, c), 5, dev)
+    a_t, a_prev, sigma, scale = 0.5, 0.7, 0.1, 7.0
+    coef = torch.tensor([a_t, a_prev, sigma, math.sqrt(1 - a_t), scale], dtype=F32, device=dev)
+    noise = _rand((b, c, h, w), 6, dev)
+    xp, p0, eo = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    ops.ddim_update(e_c, e_u, c, x, noise, coef, xp, p0, eo, b, c, h * w)
+    ec, eu = (_nchw32(v, b, h, w) for v in (e_c, e_u))
+    e = eu + scale * (ec - eu)
+    px0 = (x - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    ref = math.sqrt(a_prev) * px0 + math.sqrt(1 - a_prev - sigma ** 2) * e + sigma * noise
+    assert _err(xp, ref) <= 1e-5 and _err(p0, px0) <= 1e-5 and _err(eo, e) <= 1e-5
+
+
+def test_graph_and_profile(dev):
+    """HIP-graph capture/replay of a launch sequence with a device-side step counter; per-family event timing."""
+    from magicdance_amd import ops
+    table = torch.arange(12, dtype=F32, device=dev).reshape(4, 3)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    dst = torch.zeros(3, dtype=F32, device=dev)
+    acc = []
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = ops.Graph()
+        g.begin()
+        ops.select_row_f32(table, counter, 0, dst, 3)
+        ops.counter_add(counter, 1)
+        g.end()
+        for _ in range(4):
+            g.launch()
+            s.synchronize()
+            acc.append(dst.clone())
+        g.destroy()
+    assert torch.equal(torch.stack(acc), table)
+    ops.prof_enable(True)
+    ops.select_row_f32(table, None, 2, dst, 3)
+    torch.cuda.synchronize()
+    r = ops.prof_collect()
+    ops.prof_enable(False)
+    assert r["elementwise"]["launches"] == 1 and r["elementwise"]["ms"] > 0
+    assert np.allclose(dst.cpu().numpy(), [6, 7, 8])

@@ -9,6 +9,8 @@
 // V is consumed transposed ([H*d][tokens]); the projection GEMM writes it that way (md_igemm n_tr_begin), so K and V^T
 // tiles are plain 16-byte copies global -> registers -> LDS, prefetched one tile ahead of the MFMAs.
 // The concat [self ; bank] of the reference (attention.py:305-311) is never materialised: tiles walk segment 0 then 1.
+#include <cstdio>
+
 #include "md_common.h"
 
 namespace {
@@ -288,8 +290,11 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   g.c = p->scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   const double nkv = (double)p->n0 + (double)g.n1 * ((double)(g.n1_batches < p->batch ? g.n1_batches : p->batch) / p->batch);
+  char tag[96];
+  snprintf(tag, sizeof(tag), "B=%d H=%d nq=%d n0=%d n1=%d n1b=%d d=%d", p->batch, p->heads, p->nq, p->n0, g.n1, g.n1_batches,
+           p->d);
   md::ProfScope prof(MD_FAM_ATTENTION, s, 4.0 * p->batch * p->heads * (double)p->nq * nkv * p->d,
-                     2.0 * p->batch * p->heads * p->d * (2.0 * p->nq + 2.0 * nkv));
+                     2.0 * p->batch * p->heads * p->d * (2.0 * p->nq + 2.0 * nkv), tag);
   switch (p->d) {
     case 40: return launch<40, 2>(g, s);
     case 80: return launch<80, 2>(g, s);

@@ -13,7 +13,13 @@
 // deterministic reduce kernel that applies the same epilogue.
 //
 // Reference arithmetic replaced: see include/magicdance_hip.h (md_igemm).
+#include <cstdio>
+#include <cstdlib>
+
 #include "md_common.h"
+
+// 256 zero bytes: the source of out-of-image / out-of-range 16-byte chunks for the direct-to-LDS loader
+__device__ __attribute__((aligned(256))) unsigned char md_zero_page[256];
 
 namespace {
 
@@ -76,9 +82,27 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// GLDS = true: operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave
+// instruction, no VGPR round trip, no ds_write); the LDS image is lane-linear, so the XOR swizzle is applied to the
+// per-lane SOURCE chunk instead (lane (r, c) fetches global chunk c ^ (r & 7)); padding / k-tails read md_zero_page.
+// Address generation is branch-free: per row a 9-bit tap-validity mask and the (y, x) of tap (0,0) are computed once;
+// per k-tile a thread derives (tap, channel) of ITS fixed 16-byte k-chunk incrementally and selects pointer-or-zero.
+// LOADER 2 replaces the 64-bit pointer arithmetic + zero page by raw buffer loads: three wave-uniform descriptors
+// (a0, a1, w), per-lane 32-bit byte offsets built from 24-bit multiplies, and "out of image / past K" expressed as an
+// out-of-range offset, which the hardware turns into zeros in LDS.  (The k-tile loop was VALU-bound on address
+// generation with the pointer forms: ~900 VALU cycles vs ~540 MFMA cycles per 128x128x64 tile.)
+// STAGES > 2 (GLDS only): software pipeline with STAGES-1 k-tiles of LDS-DMA in flight.  A k-tile iteration is
+// latency-bound otherwise (~1.2 us per 64-deep tile measured with one tile of prefetch, vs ~0.1-0.2 us of MFMA work), so
+// the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
+//   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
+//   MFMAs on the landed stage.  Tiles past the end are fetched from the zero page so the outstanding count is constant.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
+  constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
+  constexpr bool BUF = LOADER == 2;    // buffer_load ... lds with hardware out-of-range -> 0 and 32-bit offsets
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(STAGES == 2 || GLDS, "deep pipeline needs the direct-to-LDS loader");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int AJ = BM / 32, WJ = BN / 32;  // 16-byte chunks per thread per k-tile
@@ -87,7 +111,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
@@ -102,77 +126,150 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const int kt_begin = kz * g.tiles_per_split;
   const int kt_end = min(g.nk, kt_begin + g.tiles_per_split);
 
-  // ---- loader role: chunk column lc (16 B of k), rows lrow + 32 j -------------------------------------
+  // ---- loader role: LDS slot (row, lc) for rows lrow + 32 j; fixed global k-chunk gc -------------------------
   const int lc = tid & 7, lrow = tid >> 3;
-  int a_iy0[AJ], a_ix0[AJ], a_b[AJ];
+  const int gc = lc ^ (lrow & 7);  // row & 7 == lrow & 7 for every row this thread serves
+  const int ups = g.ups;           // 0 / 1: source coordinate = virtual coordinate >> ups
+  const int vh = g.hin << ups, vw = g.win << ups;
+  int a_y[AJ], a_x[AJ], a_pix[AJ], a_mask[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + lrow + 32 * j;
-    if (m < g.M) {
-      const int b = m / g.tokens;
-      const int rem = m - b * g.tokens;
-      const int oy = rem / g.wout;
-      const int ox = rem - oy * g.wout;
-      a_b[j] = b;
-      a_iy0[j] = oy * g.stride - g.pad;
-      a_ix0[j] = ox * g.stride - g.pad;
-    } else {
-      a_b[j] = -1;
-      a_iy0[j] = 0;
-      a_ix0[j] = 0;
+    const int m = min(m0 + lrow + 32 * j, g.M - 1);  // rows past M are computed on a clamped row and never stored
+    const int b = m / g.tokens;
+    const int rem = m - b * g.tokens;
+    const int oy = rem / g.wout;
+    const int ox = rem - oy * g.wout;
+    a_y[j] = oy * g.stride - g.pad;
+    a_x[j] = ox * g.stride - g.pad;
+    a_pix[j] = b * g.hin * g.win;
+    int mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = a_y[j] + t / 3, ix = a_x[j] + t % 3;
+      if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) mask |= 1 << t;
     }
+    a_mask[j] = g.ksize == 3 ? mask : 1;
   }
-  const int vh = g.ups ? 2 * g.hin : g.hin, vw = g.ups ? 2 * g.win : g.win;
+  const half_t* w_ptr[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) w_ptr[j] = g.w + (long long)min(n0 + lrow + 32 * j, g.N - 1) * g.K;
+  const half_t* zero = reinterpret_cast<const half_t*>(md_zero_page);
 
+  // (tap, channel) of this thread's k-chunk, advanced by 64 channels per k-tile
+  int k_cur = kt_begin * 64 + gc * 8;
+  int tap = 0, cc = k_cur;
+  if (g.ksize == 3) {
+    tap = k_cur / g.cin;
+    cc = k_cur - tap * g.cin;
+  }
   h8 ra[AJ], rw[WJ];
-  auto load_tile = [&](int kt) {
-    const int k = kt * 64 + lc * 8;
-    const bool kvalid = k < g.K;
-    int tap = 0, cc = k;
-    if (g.ksize == 3) {
-      tap = k / g.cin;
-      cc = k - tap * g.cin;
-    }
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const half_t* src = g.a0;
-    int cs = g.c0, ccc = cc;
-    if (cc >= g.c0) {
-      src = g.a1;
-      cs = g.c1;
-      ccc = cc - g.c0;
-    }
+  [[maybe_unused]] unsigned w_off[WJ];
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-      if (kvalid && a_b[j] >= 0 && iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
-        const int sy = g.ups ? (iy >> 1) : iy, sx = g.ups ? (ix >> 1) : ix;
-        const long long off = ((long long)(a_b[j] * g.hin + sy) * g.win + sx) * cs + ccc;
-        v = *reinterpret_cast<const h8*>(src + off);
+  for (int j = 0; j < WJ; ++j) w_off[j] = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u;
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(g.a0), 0, g.batch * g.hin * g.win * g.c0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(g.a1 ? g.a1 : g.a0), 0, g.batch * g.hin * g.win * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), 0, g.N * g.K * 2, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;  // beyond any tensor: the load returns zeros
+
+  // BUF loader: the launcher guarantees cin % 64 == 0 and c0 % 64 == 0, so a 64-channel k-tile lies in ONE tap of ONE
+  // source: tap / source / channel base are wave-uniform scalars advanced per tile (no waterfall on the descriptor).
+  int kt_u = kt_begin * 64, tap_u = 0, cc_u = kt_begin * 64;
+  if (g.ksize == 3) {
+    tap_u = kt_u / g.cin;
+    cc_u = kt_u - tap_u * g.cin;
+  }
+  auto fetch_tile = [&](int stage, bool tile_valid = true) {  // loads the tile at (k_cur, tap, cc), then advances
+    char* As = smem + stage * STAGE_BYTES;
+    char* Ws = As + BM * 128;
+    if constexpr (BUF) {
+      const bool kvalid = tile_valid && kt_u < g.K;  // uniform (K % 64 == 0 here)
+      const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
+      const bool second = cc_u >= g.c0;
+      const unsigned cs = second ? g.c1 : g.c0;
+      const unsigned ccc = (unsigned)(second ? cc_u - g.c0 : cc_u) + gc * 8;
+      const int tapbit = kvalid ? (1 << tap_u) : 0;
+      unsigned voff[AJ];
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int sy = (a_y[j] + dy) >> ups, sx = (a_x[j] + dx) >> ups;
+        const unsigned pix = (unsigned)(a_pix[j] + (int)__mul24(sy, g.win) + sx);
+        const unsigned v = (__umul24(pix, cs) + ccc) * 2u;
+        voff[j] = (a_mask[j] & tapbit) ? v : OOB;
       }
-      ra[j] = v;
-    }
+      if (second) {
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int n = n0 + lrow + 32 * j;
-      if (kvalid && n < g.N) v = *reinterpret_cast<const h8*>(g.w + (long long)n * g.K + k);
-      rw[j] = v;
+        for (int j = 0; j < AJ; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                   16, voff[j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                   16, voff[j], 0, 0, 0);
+      }
+      const unsigned kb = kvalid ? (unsigned)(kt_u + gc * 8) * 2u : OOB;
+#pragma unroll
+      for (int j = 0; j < WJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
+                                                 16, kvalid ? w_off[j] + kb : OOB, 0, 0, 0);
+      kt_u += 64;
+      cc_u += 64;
+      if (g.ksize == 3 && cc_u >= g.cin) {
+        cc_u -= g.cin;
+        ++tap_u;
+      }
+      return;
+    }
+    const bool kvalid = tile_valid && k_cur < g.K;
+    const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+    const bool second = cc >= g.c0;
+    const int cs = second ? g.c1 : g.c0;
+    const int ccc = second ? cc - g.c0 : cc;
+    {
+      const half_t* src = second ? g.a1 : g.a0;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int sy = (a_y[j] + dy) >> ups, sx = (a_x[j] + dx) >> ups;
+        // branch-free pointer-or-zero-page: mask the element offset, select the base
+        const long long okmask = -(long long)((kvalid ? (a_mask[j] >> tap) : 0) & 1);
+        const long long off = ((long long)(a_pix[j] + sy * g.win + sx) * cs + ccc) & okmask;
+        const half_t* p = (okmask ? src : zero) + off;
+        if constexpr (GLDS) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                           (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16, 0, 0);
+        } else {
+          ra[j] = *reinterpret_cast<const h8*>(p);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        const half_t* p = (kvalid ? w_ptr[j] : zero) + (kvalid ? k_cur : 0);
+        if constexpr (GLDS) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                           (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16, 0, 0);
+        } else {
+          rw[j] = *reinterpret_cast<const h8*>(p);
+        }
+      }
+    }
+    k_cur += 64;
+    cc += 64;
+    if (g.ksize == 3) {
+      while (cc >= g.cin) {
+        cc -= g.cin;
+        ++tap;
+      }
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage) {  // register-staged variant only: LDS slot (row, lc) <- chunk gc
     char* As = smem + stage * STAGE_BYTES;
     char* Ws = As + BM * 128;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int row = lrow + 32 * j;
-      *reinterpret_cast<h8*>(As + row * 128 + ((lc ^ (row & 7)) << 4)) = ra[j];
-    }
+    for (int j = 0; j < AJ; ++j) *reinterpret_cast<h8*>(As + (lrow + 32 * j) * 128 + (lc << 4)) = ra[j];
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const int row = lrow + 32 * j;
-      *reinterpret_cast<h8*>(Ws + row * 128 + ((lc ^ (row & 7)) << 4)) = rw[j];
-    }
+    for (int j = 0; j < WJ; ++j) *reinterpret_cast<h8*>(Ws + (lrow + 32 * j) * 128 + (lc << 4)) = rw[j];
   };
 
   f4 acc[NF][MF];
@@ -181,16 +278,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int stage = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);
+  auto compute_tile = [&](int stage) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Ws = As + BM * 128;
 #pragma unroll
@@ -213,8 +301,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         for (int j = 0; j < MF; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(stage ^ 1);
-    __syncthreads();
+  };
+
+  if constexpr (GLDS && STAGES > 2) {
+    constexpr int LPT = AJ + WJ;  // LDS-DMA instructions per thread per k-tile
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) fetch_tile(s, kt_begin + s < kt_end);
+    int stage = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");  // tile kt has landed (this wave's part)
+      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the stage refilled next
+      const int refill = stage == 0 ? STAGES - 1 : stage - 1;
+      fetch_tile(refill, kt + STAGES - 1 < kt_end);
+      compute_tile(stage);
+      stage = stage == STAGES - 1 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the zero-page tail fetches before LDS is released
+  } else {
+    if constexpr (GLDS) {
+      if (kt_begin < kt_end) fetch_tile(0);
+    } else {
+      if (kt_begin < kt_end) {
+        fetch_tile(0);
+        store_tile(0);
+      }
+      __syncthreads();
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int stage = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if constexpr (GLDS) {
+        __syncthreads();  // tile kt has landed (vmcnt(0) precedes the barrier); every wave is done with stage^1
+        if (more) fetch_tile(stage ^ 1);
+      } else {
+        if (more) fetch_tile(stage ^ 1);
+      }
+      compute_tile(stage);
+      if constexpr (!GLDS) {
+        if (more) store_tile(stage ^ 1);
+        __syncthreads();
+      }
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
@@ -269,6 +396,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       epi_store4(g, m, b, n, acc[i][j]);
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // Deterministic split-K reduction + epilogue: one thread per (m, 4 columns).
@@ -283,18 +411,35 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
   epi_store4(g, m, m / g.tokens, n, s);
 }
 
+// config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
+// families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
+//           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages
+const float kTileEff[4] = {1.00f, 0.85f, 0.85f, 0.70f};
+const int kTileBM[4] = {128, 128, 64, 64}, kTileBN[4] = {128, 64, 128, 64};
+constexpr int kNumFamilies = 5;
+constexpr int kNumCfgs = 4 * kNumFamilies;
 struct TileCfg {
   int bm, bn;
   float eff;
 };
-const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 64, 0.85f}, {64, 128, 0.85f}, {64, 64, 0.70f}};
-constexpr int kNumCfgs = 4;
+inline TileCfg cfg_of(int c) { return TileCfg{kTileBM[c & 3], kTileBN[c & 3], kTileEff[c & 3]}; }
+// default loader family: MD_IGEMM_LOADER = 0..4
+int g_default_loader = [] {
+  const char* e = getenv("MD_IGEMM_LOADER");
+  return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
+}();
 
-template <int BM, int BN, int WMv, int WNv>
+template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
-  const size_t lds = 2 * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -309,7 +454,7 @@ int validate(const md_igemm_params* p) {
   if (p->n <= 0 || (p->n & 3) || (p->ld_out & 3)) return MD_ERR_BAD_ARG;
   if (p->batch <= 0 || p->hin <= 0 || p->win <= 0 || p->hout <= 0 || p->wout <= 0) return MD_ERR_BAD_ARG;
   if (p->res && (p->ld_res & 3)) return MD_ERR_BAD_ARG;
-  if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin & 15)) return MD_ERR_BAD_ARG;
+  if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
   if (p->bias_batch_stride & 3) return MD_ERR_BAD_ARG;
   if (p->act == MD_ACT_GEGLU) {
@@ -324,12 +469,17 @@ int validate(const md_igemm_params* p) {
 void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_bytes, int* cfg_out, int* split_out) {
   const int nk = (K + 63) / 64;
   double best = 1e30;
-  int bc = 3, bs = 1;
+  int bc = 4 * g_default_loader + 3, bs = 1;
+  if (g_default_loader >= 3 && !(((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0))) bc = 7;
+  // the buffer-descriptor loader needs tile-uniform (tap, source): 64-channel k-tiles must not straddle either
+  const bool buf_ok = ((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0);
+  const int fam = (g_default_loader >= 3 && !buf_ok) ? 1 : g_default_loader;
   for (int c = 0; c < kNumCfgs; ++c) {
     if (p->force_cfg >= 0 && c != p->force_cfg) continue;
-    const long long tm = (M + kCfgs[c].bm - 1) / kCfgs[c].bm, tn = (N + kCfgs[c].bn - 1) / kCfgs[c].bn;
+    if (p->force_cfg < 0 && c / 4 != fam) continue;
+    const long long tm = (M + cfg_of(c).bm - 1) / cfg_of(c).bm, tn = (N + cfg_of(c).bn - 1) / cfg_of(c).bn;
     const long long blocks = tm * tn;
-    const double rate_cu = 2.5e15 / 256.0 * 0.35 * kCfgs[c].eff;  // flop/s per CU we expect from this tile
+    const double rate_cu = 2.5e15 / 256.0 * 0.35 * cfg_of(c).eff;  // flop/s per CU we expect from this tile
     for (int s = 1; s <= 32; s = (s < 4 ? s + 1 : s * 2)) {
       if (p->force_splitk > 0 && s != p->force_splitk) continue;
       if (s > 1) {
@@ -339,7 +489,7 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
       }
       const int tps = (nk + s - 1) / s;
       const long long waves = (blocks * s + 255) / 256;
-      double t = (double)waves * (2.0 * kCfgs[c].bm * kCfgs[c].bn * (double)tps * 64.0) / rate_cu + 2e-6;
+      double t = (double)waves * (2.0 * cfg_of(c).bm * cfg_of(c).bn * (double)tps * 64.0) / rate_cu + 2e-6;
       if (s > 1) t += (double)M * N * 4.0 * (s + 1) / 3e12 + 3e-6;
       if (t < best) {
         best = t;
@@ -403,21 +553,42 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.ws = (float*)p->ws;
   int cfg, split;
   choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split);
+  if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
-  g.tiles_m = (g.M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm;
-  g.tiles_n = (g.N + kCfgs[cfg].bn - 1) / kCfgs[cfg].bn;
+  g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
+  g.tiles_n = (g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn;
   hipStream_t s = (hipStream_t)stream;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d", M, g.N, g.K, g.ksize, g.stride, g.ups,
+           cfg, split);
   md::ProfScope prof(MD_FAM_IGEMM, s, 2.0 * (double)M * g.N * g.K,
-                     (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0);
+                     (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0, tag);
   int rc;
   switch (cfg) {
-    case 0: rc = launch_cfg<128, 128, 2, 2>(g, s); break;
-    case 1: rc = launch_cfg<128, 64, 2, 2>(g, s); break;
-    case 2: rc = launch_cfg<64, 128, 2, 2>(g, s); break;
-    default: rc = launch_cfg<64, 64, 2, 2>(g, s); break;
+    case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
+    case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
+    case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;
+    case 3: rc = launch_cfg<64, 64, 2, 2, 0, 2>(g, s); break;
+    case 4: rc = launch_cfg<128, 128, 2, 2, 1, 2>(g, s); break;
+    case 5: rc = launch_cfg<128, 64, 2, 2, 1, 2>(g, s); break;
+    case 6: rc = launch_cfg<64, 128, 2, 2, 1, 2>(g, s); break;
+    case 7: rc = launch_cfg<64, 64, 2, 2, 1, 2>(g, s); break;
+    case 8: rc = launch_cfg<128, 128, 2, 2, 1, 4>(g, s); break;
+    case 9: rc = launch_cfg<128, 64, 2, 2, 1, 4>(g, s); break;
+    case 10: rc = launch_cfg<64, 128, 2, 2, 1, 4>(g, s); break;
+    case 11: rc = launch_cfg<64, 64, 2, 2, 1, 4>(g, s); break;
+    case 12: rc = launch_cfg<128, 128, 2, 2, 2, 2>(g, s); break;
+    case 13: rc = launch_cfg<128, 64, 2, 2, 2, 2>(g, s); break;
+    case 14: rc = launch_cfg<64, 128, 2, 2, 2, 2>(g, s); break;
+    case 15: rc = launch_cfg<64, 64, 2, 2, 2, 2>(g, s); break;
+    case 16: rc = launch_cfg<128, 128, 2, 2, 2, 3>(g, s); break;
+    case 17: rc = launch_cfg<128, 64, 2, 2, 2, 3>(g, s); break;
+    case 18: rc = launch_cfg<64, 128, 2, 2, 2, 3>(g, s); break;
+    case 19: rc = launch_cfg<64, 64, 2, 2, 2, 3>(g, s); break;
+    default: return MD_ERR_BAD_ARG;
   }
   if (rc != MD_OK) return rc;
   if (split > 1) {

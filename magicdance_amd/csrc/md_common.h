@@ -34,7 +34,7 @@ struct ProfScope {
   hipStream_t stream;
   hipEvent_t start;
   bool active;
-  ProfScope(int family, hipStream_t stream, double flops, double bytes);
+  ProfScope(int family, hipStream_t stream, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
 };
 

@@ -1,6 +1,9 @@
 // Runtime pieces of libmagicdance_hip.so: ABI version, HIP-graph capture of a launch sequence (one DDIM step =
 // ~2.5k kernel launches replayed from a single hipGraphLaunch), and per-kernel-family HIP-event timing used by
 // bench.py's roofline leg.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -15,13 +18,14 @@ struct ProfRec {
   int family;
   hipEvent_t start, stop;
   double flops, bytes;
+  char tag[96];
 };
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
 }  // namespace
 
-ProfScope::ProfScope(int fam, hipStream_t s, double flops, double bytes)
+ProfScope::ProfScope(int fam, hipStream_t s, double flops, double bytes, const char* tag)
     : family(fam), stream(s), start(nullptr), active(false) {
   if (!g_prof_on) return;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -30,6 +34,11 @@ ProfScope::ProfScope(int fam, hipStream_t s, double flops, double bytes)
   r.family = fam;
   r.flops = flops;
   r.bytes = bytes;
+  r.tag[0] = 0;
+  if (tag) {
+    strncpy(r.tag, tag, sizeof(r.tag) - 1);
+    r.tag[sizeof(r.tag) - 1] = 0;
+  }
   if (hipEventCreate(&r.start) != hipSuccess) return;
   if (hipEventCreate(&r.stop) != hipSuccess) {
     (void)hipEventDestroy(r.start);
@@ -102,6 +111,9 @@ extern "C" int md_prof_collect(double* ms, int64_t* launches, double* flops, dou
     if (bytes) bytes[i] = 0.0;
   }
   int rc = MD_OK;
+  // MD_PROF_DUMP=<path>: append one line per launch (family, ms, flops, bytes, shape tag) for offline tuning
+  const char* dump_path = getenv("MD_PROF_DUMP");
+  FILE* dump = dump_path ? fopen(dump_path, "a") : nullptr;
   for (auto& r : md::g_prof_recs) {
     float t = 0.f;
     hipError_t e = hipEventSynchronize(r.stop);
@@ -113,10 +125,12 @@ extern "C" int md_prof_collect(double* ms, int64_t* launches, double* flops, dou
       if (launches) launches[r.family] += 1;
       if (flops) flops[r.family] += r.flops;
       if (bytes) bytes[r.family] += r.bytes;
+      if (dump) fprintf(dump, "%d\t%.6f\t%.0f\t%.0f\t%s\n", r.family, (double)t, r.flops, r.bytes, r.tag);
     }
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
+  if (dump) fclose(dump);
   md::g_prof_recs.clear();
   return rc;
 }

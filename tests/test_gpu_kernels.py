@@ -59,7 +59,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_igemm_conv(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cins, h, w, cout, k, stride, ups = case
@@ -74,6 +74,8 @@ def test_igemm_conv(dev, case, cfg):
         xin = F.interpolate(xin, scale_factor=2, mode="nearest")
     ref = F.conv2d(xin, wt.half().float(), bias, stride=stride, padding=k // 2)
     ho, wo = ref.shape[2], ref.shape[3]
+    if cfg >= 12 and (cin % 64 or cins[0] % 64):
+        pytest.skip("buffer-descriptor loader needs 64-channel-aligned sources (the launcher routes these to family 1)")
     out = torch.empty((b, ho * wo, cout), dtype=F16, device=dev)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
     ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride, ups=ups,

@@ -33,6 +33,7 @@ struct IgemmArgs {
   int M, N, K;
   int nk, splitk, tiles_per_split;
   int tiles_m, tiles_n;
+  unsigned div_tok_mul, div_tok_sh, div_w_mul, div_w_sh;  // exact n / tokens and n / wout for n < 2^24 (fast_div)
   // epilogue
   const float* bias;
   long long bias_bs;
@@ -47,6 +48,11 @@ struct IgemmArgs {
   int ld_t;
   float* ws;
 };
+
+// n / d for n < 2^24: q = (n * mul) >> sh with mul = floor(2^sh / d) + 1, sh = 24 + ceil(log2 d) (host side below)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
+  return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
+}
 
 // Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed).
 __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int n, f4 v) {
@@ -135,20 +141,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int m = min(m0 + lrow + 32 * j, g.M - 1);  // rows past M are computed on a clamped row and never stored
-    const int b = m / g.tokens;
+    const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
     const int rem = m - b * g.tokens;
-    const int oy = rem / g.wout;
+    const int oy = fast_div(rem, g.div_w_mul, g.div_w_sh);
     const int ox = rem - oy * g.wout;
     a_y[j] = oy * g.stride - g.pad;
     a_x[j] = ox * g.stride - g.pad;
     a_pix[j] = b * g.hin * g.win;
-    int mask = 0;
+    int mask = 1;
+    if (g.ksize == 3) {  // bit t = tap (t/3, t%3) inside the (virtual) image: 3 column bits replicated per valid row
+      int cx = 0;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int iy = a_y[j] + t / 3, ix = a_x[j] + t % 3;
-      if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) mask |= 1 << t;
+      for (int d = 0; d < 3; ++d) cx |= ((unsigned)(a_x[j] + d) < (unsigned)vw) ? (1 << d) : 0;
+      mask = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) mask |= ((unsigned)(a_y[j] + d) < (unsigned)vh) ? (cx << (3 * d)) : 0;
     }
-    a_mask[j] = g.ksize == 3 ? mask : 1;
+    a_mask[j] = mask;
   }
   const half_t* w_ptr[WJ];
 #pragma unroll
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   for (int j = 0; j < MF; ++j) {
     const int m = m0 + wm * WTM + j * 16 + lr;
     if (m >= g.M) continue;
-    const int b = m / g.tokens;
+    const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int n = n0 + wn * WTN + i * 16 + lg * 4;
@@ -444,6 +453,13 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   return MD_OK;
 }
 
+void fast_div_magic(unsigned d, unsigned* mul, unsigned* sh) {
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;
+  *sh = 24 + l;
+  *mul = (unsigned)(((unsigned long long)1 << (24 + l)) / d) + 1u;
+}
+
 int validate(const md_igemm_params* p) {
   if (!p || !p->a0 || !p->w || !p->out) return MD_ERR_BAD_ARG;
   if (p->ksize != 1 && p->ksize != 3) return MD_ERR_UNSUPPORTED;
@@ -465,9 +481,34 @@ int validate(const md_igemm_params* p) {
   return MD_OK;
 }
 
-// Pick tile config + split-K from a crude time model (tunable through force_cfg / force_splitk).
+// Measured-best (config, split-K) per layer shape, generated on an MI355X by tools/tune_igemm.py
+struct TunedEntry {
+  int m, n, k, ksize, stride, ups, cfg, split;
+};
+const TunedEntry kTuned[] = {
+#include "igemm_tuned.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
+int g_use_tuned = [] {
+  const char* e = getenv("MD_IGEMM_TUNED");
+  return (e && e[0] == '0') ? 0 : 1;
+}();
+
+// Pick tile config + split-K: tuned table first, otherwise a crude time model (overridable: force_cfg / force_splitk).
 void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_bytes, int* cfg_out, int* split_out) {
   const int nk = (K + 63) / 64;
+  if (g_use_tuned && p->force_cfg < 0 && p->force_splitk <= 0) {
+    for (const TunedEntry* t = kTuned; t->m; ++t) {
+      if (t->m == M && t->n == N && t->k == K && t->ksize == p->ksize && t->stride == p->stride && t->ups == p->ups) {
+        const bool ok_split = t->split == 1 || (p->act != MD_ACT_GEGLU && (long long)t->split * M * N * 4 <= ws_bytes);
+        const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
+        if (ok_split && ok_buf) {
+          *cfg_out = t->cfg;
+          *split_out = t->split;
+          return;
+        }
+      }
+    }
+  }
   double best = 1e30;
   int bc = 4 * g_default_loader + 3, bs = 1;
   if (g_default_loader >= 3 && !(((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0))) bc = 7;
@@ -534,8 +575,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.pad = p->ksize / 2;
   g.w = (const half_t*)p->w;
   const long long M = (long long)p->batch * g.tokens;
-  if (M > 0x7fffffffLL) return MD_ERR_BAD_ARG;
+  if (M >= (1LL << 24)) return MD_ERR_BAD_ARG;  // fast_div domain
   g.M = (int)M;
+  fast_div_magic((unsigned)g.tokens, &g.div_tok_mul, &g.div_tok_sh);
+  fast_div_magic((unsigned)g.wout, &g.div_w_mul, &g.div_w_sh);
   g.N = p->n;
   g.K = p->ksize * p->ksize * g.cin;
   g.nk = (g.K + 63) / 64;
@@ -561,9 +604,9 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
   g.tiles_n = (g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn;
   hipStream_t s = (hipStream_t)stream;
-  char tag[96];
-  snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d", M, g.N, g.K, g.ksize, g.stride, g.ups,
-           cfg, split);
+  char tag[128];
+  snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d B=%d h=%d w=%d c0=%d c1=%d act=%d", M, g.N, g.K,
+           g.ksize, g.stride, g.ups, cfg, split, g.batch, g.hin, g.win, g.c0, g.c1, g.act);
   md::ProfScope prof(MD_FAM_IGEMM, s, 2.0 * (double)M * g.N * g.K,
                      (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0, tag);
   int rc;

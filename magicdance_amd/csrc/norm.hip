@@ -13,105 +13,179 @@
 
 namespace {
 
-constexpr int GN_PIX = 1024;     // pixels per stats block
-constexpr int GN_ITEMS = 2048;   // 16-byte chunks per apply block
+constexpr int GN_ITEMS = 512;    // 16-byte chunks per apply block (2 per thread: the loop is latency-bound, not table-bound)
+constexpr int GN_MAX_TY = 8;
 
 struct GnArgs {
   const half_t* x0;
   const half_t* x1;
   int c0, c1, c, cpg, groups;
-  int batch, hw, nchunks;
+  int batch, hw, nchunks, pix_per_chunk;
+  int ch8, ty;            // stats block = ch8 x ty threads: thread (tx, ty) owns 8 channels tx*8.. of pixels ty, ty+TY, ..
+  unsigned cpg_magic;     // c / cpg == (c * cpg_magic) >> 20 for every c < C (checked on the host)
   float eps;
   const float* gamma;
   const float* beta;
   int silu;
   half_t* out;
-  float* ws;  // [batch][groups][nchunks][2]
+  float* ws;  // [batch][nchunks][groups][2]
 };
 
-__global__ __launch_bounds__(256) void gn_stats(const GnArgs g) {
-  const int chunk = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
-  const int p_begin = chunk * GN_PIX, p_end = min(g.hw, p_begin + GN_PIX);
-  const int cbeg = grp * g.cpg;
-  const int pairs = g.cpg >> 1;
-  float s = 0.f, ss = 0.f;
-  for (int p = p_begin + threadIdx.x; p < p_end; p += 256) {
-    const long long pix = (long long)b * g.hw + p;
-    for (int i = 0; i < pairs; ++i) {
-      const int c = cbeg + 2 * i;
-      const h2 v = (c < g.c0) ? *reinterpret_cast<const h2*>(g.x0 + pix * g.c0 + c)
-                              : *reinterpret_cast<const h2*>(g.x1 + pix * g.c1 + (c - g.c0));
-      const float a = (float)v[0], d = (float)v[1];
-      s += a + d;
-      ss += a * a + d * d;
+// stats: fully coalesced -- a block streams [pix_per_chunk][C] once with 16-byte loads, per-channel fp32 partials stay in
+// registers, then a fixed-order reduction over the block's pixel lanes and the channels of each group (deterministic).
+__global__ __launch_bounds__(512) void gn_stats(const GnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][ty][C]
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int tx = threadIdx.x % g.ch8, ty = threadIdx.x / g.ch8;
+  const int p_begin = chunk * g.pix_per_chunk, p_end = min(g.hw, p_begin + g.pix_per_chunk);
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+  const int c = tx * 8;
+  if (ty < g.ty) {
+#pragma unroll 4
+    for (int p = p_begin + ty; p < p_end; p += g.ty) {
+      const long long pix = (long long)b * g.hw + p;
+      const h8 v = (c < g.c0) ? *reinterpret_cast<const h8*>(g.x0 + pix * g.c0 + c)
+                              : *reinterpret_cast<const h8*>(g.x1 + pix * g.c1 + (c - g.c0));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[e];
+        s[e] += f;
+        ss[e] += f * f;
+      }
+    }
+    float* r0 = red + ty * g.c + c;
+    float* r1 = red + (g.ty + ty) * g.c + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r0[e] = s[e];
+      r1[e] = ss[e];
     }
   }
-  s = md::wave_sum(s);
-  ss = md::wave_sum(ss);
-  __shared__ float red[8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    red[wave] = s;
-    red[4 + wave] = ss;
-  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float* o = g.ws + (((long long)b * g.groups + grp) * g.nchunks + chunk) * 2;
-    o[0] = red[0] + red[1] + red[2] + red[3];
-    o[1] = red[4] + red[5] + red[6] + red[7];
+  // 2 * groups (sum | sumsq) reductions, one per thread, fixed order
+  if ((int)threadIdx.x < 2 * g.groups) {
+    const int which = threadIdx.x / g.groups, grp = threadIdx.x % g.groups;
+    float acc = 0.f;
+    for (int t = 0; t < g.ty; ++t) {
+      const float* r = red + (which * g.ty + t) * g.c + grp * g.cpg;
+      for (int i = 0; i < g.cpg; ++i) acc += r[i];
+    }
+    g.ws[(((long long)b * g.nchunks + chunk) * g.groups + grp) * 2 + which] = acc;
   }
 }
 
+// apply: every global load this thread needs (its <= 2 input chunks, the partials it folds, gamma/beta of the table
+// entries it builds) is issued up front so their latencies overlap; the only serial chain left is LDS + barriers.
 __global__ __launch_bounds__(256) void gn_apply(const GnArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[c], shift[c], then mean/rstd[groups]
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[c], shift[c], mean/rstd[groups], partial[8][2*groups]
   float* scale = tab;
   float* shift = tab + g.c;
   float* mean = tab + 2 * g.c;
   float* rstd = mean + g.groups;
+  float* part = rstd + g.groups;
   const int b = blockIdx.y;
-  if (threadIdx.x < g.groups) {
-    const float* pw = g.ws + ((long long)b * g.groups + threadIdx.x) * g.nchunks * 2;
-    float s = 0.f, ss = 0.f;
-    for (int i = 0; i < g.nchunks; ++i) {
-      s += pw[2 * i];
-      ss += pw[2 * i + 1];
+  const int ch8 = g.ch8;
+  const int total = g.hw * ch8;
+  const int begin = blockIdx.x * GN_ITEMS;
+  const int end = min(begin + GN_ITEMS, total);
+  constexpr int NI = GN_ITEMS / 256;
+  // (1) this thread's input chunks
+  h8 v[NI];
+  int pc[NI], cc8[NI];
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int it = begin + threadIdx.x + 256 * u;
+    const int p = it / ch8, cc = it - p * ch8;
+    pc[u] = p;
+    cc8[u] = cc * 8;
+    if (it < end) {
+      const long long pix = (long long)b * g.hw + p;
+      v[u] = (cc8[u] < g.c0) ? *reinterpret_cast<const h8*>(g.x0 + pix * g.c0 + cc8[u])
+                             : *reinterpret_cast<const h8*>(g.x1 + pix * g.c1 + (cc8[u] - g.c0));
+    }
+  }
+  // (2) partial sums: 8 lanes per (group, which), <= 32 chunks per sample
+  const int ng2 = 2 * g.groups;
+  for (int i = threadIdx.x; i < 8 * ng2; i += 256) {
+    const int lane8 = i / ng2, gw = i % ng2;  // gw = grp*2 + which
+    float w4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = lane8 + 8 * u;
+      if (ch < g.nchunks) w4[u] = g.ws[((long long)b * g.nchunks + ch) * ng2 + gw];
+    }
+    part[lane8 * ng2 + gw] = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+  }
+  // (3) gamma / beta of the table entries this thread builds (C <= 4096 -> at most 16 per thread)
+  float gm[16], bt[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = threadIdx.x + 256 * u;
+    if (c < g.c) {
+      gm[u] = g.gamma[c];
+      bt[u] = g.beta[c];
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < g.groups) {
+    float sm = 0.f, sq = 0.f;
+    for (int l = 0; l < 8; ++l) {
+      sm += part[l * ng2 + threadIdx.x * 2];
+      sq += part[l * ng2 + threadIdx.x * 2 + 1];
     }
     const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
-    const float mu = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mu * mu, 0.f);
+    const float mu = sm * inv_n;
+    const float var = fmaxf(sq * inv_n - mu * mu, 0.f);
     mean[threadIdx.x] = mu;
     rstd[threadIdx.x] = rsqrtf(var + g.eps);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < g.c; c += 256) {
-    const int grp = c / g.cpg;
-    const float sc = rstd[grp] * g.gamma[c];
-    scale[c] = sc;
-    shift[c] = g.beta[c] - mean[grp] * sc;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = threadIdx.x + 256 * u;
+    if (c < g.c) {
+      const int grp = (int)(((unsigned)c * g.cpg_magic) >> 20);
+      const float sc = rstd[grp] * gm[u];
+      scale[c] = sc;
+      shift[c] = bt[u] - mean[grp] * sc;
+    }
   }
   __syncthreads();
-  const int ch8 = g.c >> 3;
-  const long long total = (long long)g.hw * ch8;
-  const long long begin = (long long)blockIdx.x * GN_ITEMS;
-  const long long end = begin + GN_ITEMS < total ? begin + GN_ITEMS : total;
-  for (long long it = begin + threadIdx.x; it < end; it += 256) {
-    const int p = (int)(it / ch8);
-    const int c = (int)(it - (long long)p * ch8) * 8;
-    const long long pix = (long long)b * g.hw + p;
-    const h8 v = (c < g.c0) ? *reinterpret_cast<const h8*>(g.x0 + pix * g.c0 + c)
-                            : *reinterpret_cast<const h8*>(g.x1 + pix * g.c1 + (c - g.c0));
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int it = begin + threadIdx.x + 256 * u;
+    if (it >= end) continue;
+    const int c = cc8[u];
     const f4 s0 = *reinterpret_cast<const f4*>(scale + c), s1 = *reinterpret_cast<const f4*>(scale + c + 4);
     const f4 h0 = *reinterpret_cast<const f4*>(shift + c), h1 = *reinterpret_cast<const f4*>(shift + c + 4);
     h8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float sc = i < 4 ? s0[i] : s1[i - 4], sh = i < 4 ? h0[i] : h1[i - 4];
-      float y = (float)v[i] * sc + sh;
+      float y = (float)v[u][i] * sc + sh;
       if (g.silu) y = md::silu_f(y);
       o[i] = (half_t)y;
     }
-    *reinterpret_cast<h8*>(g.out + pix * g.c + c) = o;
+    *reinterpret_cast<h8*>(g.out + ((long long)b * g.hw + pc[u]) * g.c + c) = o;
   }
+}
+
+// stats grid geometry shared by the launcher and the workspace query
+inline void gn_geometry(int batch, int hw, int c, int* ty, int* pix_per_chunk, int* nchunks) {
+  const int ch8 = c >> 3;
+  int t = 512 / ch8;
+  if (t < 1) t = 1;
+  if (t > GN_MAX_TY) t = GN_MAX_TY;
+  // at most 32 partials per sample (every apply block folds them), at least ty pixels per block
+  (void)batch;
+  int ppc = (hw + 31) / 32;
+  if (ppc < t) ppc = t;
+  if (ppc > hw) ppc = hw;
+  *ty = t;
+  *pix_per_chunk = ppc;
+  *nchunks = (hw + ppc - 1) / ppc;
 }
 
 // LayerNorm: one wave per row, row kept in registers (c <= 2048), two-pass statistics in fp32.
@@ -169,7 +243,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 }  // namespace
 
 extern "C" int64_t md_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups) {
-  const int64_t nchunks = (hw + GN_PIX - 1) / GN_PIX;
+  // upper bound over channel counts: the stats grid never uses more than hw chunks per sample
+  int64_t nchunks = 32;
   return (int64_t)batch * groups * nchunks * 2 * sizeof(float);
 }
 
@@ -177,9 +252,8 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   if (!p || !p->x0 || !p->gamma || !p->beta || !p->out || !p->ws) return MD_ERR_BAD_ARG;
   const int c = p->c0 + p->c1;
   if (p->c0 <= 0 || (p->c0 & 7) || p->c1 < 0 || (p->c1 & 7) || ((p->c1 > 0) != (p->x1 != nullptr))) return MD_ERR_BAD_ARG;
-  if (p->groups <= 0 || p->groups > 256 || c % p->groups || ((c / p->groups) & 1)) return MD_ERR_UNSUPPORTED;
+  if (p->groups <= 0 || p->groups > 128 || c % p->groups || c > 4096) return MD_ERR_UNSUPPORTED;
   if (p->batch <= 0 || p->hw <= 0) return MD_ERR_BAD_ARG;
-  if (p->ws_bytes < md_groupnorm_workspace_bytes(p->batch, p->hw, p->groups)) return MD_ERR_WORKSPACE;
   GnArgs g;
   g.x0 = (const half_t*)p->x0;
   g.x1 = (const half_t*)p->x1;
@@ -190,7 +264,14 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   g.cpg = c / p->groups;
   g.batch = p->batch;
   g.hw = p->hw;
-  g.nchunks = (p->hw + GN_PIX - 1) / GN_PIX;
+  g.ch8 = c >> 3;
+  if (g.ch8 > 512) return MD_ERR_UNSUPPORTED;
+  gn_geometry(p->batch, p->hw, c, &g.ty, &g.pix_per_chunk, &g.nchunks);
+  if ((int64_t)p->batch * g.nchunks * p->groups * 2 * (int64_t)sizeof(float) > p->ws_bytes) return MD_ERR_WORKSPACE;
+  // exact c / cpg by multiply-shift, verified for this (C, cpg)
+  g.cpg_magic = ((1u << 20) + (unsigned)g.cpg - 1u) / (unsigned)g.cpg;
+  for (int ch = 0; ch < c; ++ch)
+    if ((int)(((unsigned)ch * g.cpg_magic) >> 20) != ch / g.cpg) return MD_ERR_UNSUPPORTED;
   g.eps = p->eps;
   g.gamma = p->gamma;
   g.beta = p->beta;
@@ -199,11 +280,13 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   g.ws = (float*)p->ws;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_NORM, s, 0.0, (double)p->batch * p->hw * c * 2.0 * 3.0);
-  hipLaunchKernelGGL(gn_stats, dim3(g.nchunks, g.groups, g.batch), dim3(256), 0, s, g);
+  const int threads = g.ch8 * g.ty;
+  const size_t lds1 = 2 * (size_t)g.ty * c * sizeof(float);
+  hipLaunchKernelGGL(gn_stats, dim3(g.nchunks, g.batch), dim3(threads < 64 ? 64 : threads), lds1, s, g);
   MD_HIP_CHECK(hipGetLastError());
-  const long long items = (long long)p->hw * (c >> 3);
-  const size_t lds = (2 * (size_t)c + 2 * (size_t)p->groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_apply, dim3((unsigned)((items + GN_ITEMS - 1) / GN_ITEMS), g.batch), dim3(256), lds, s, g);
+  const long long items = (long long)p->hw * g.ch8;
+  const size_t lds2 = (2 * (size_t)c + 2 * (size_t)p->groups + 16 * (size_t)p->groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_apply, dim3((unsigned)((items + GN_ITEMS - 1) / GN_ITEMS), g.batch), dim3(256), lds2, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }

@@ -18,7 +18,7 @@ struct ProfRec {
   int family;
   hipEvent_t start, stop;
   double flops, bytes;
-  char tag[96];
+  char tag[128];
 };
 bool g_prof_on = false;
 std::mutex g_prof_mu;

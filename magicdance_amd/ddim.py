@@ -12,6 +12,8 @@ Mirror of ``DDIMSampler_ReferenceOnly`` (model_lib/ControlNet/ldm/models/diffusi
     + fused CFG/DDIM update; the timestep and schedule coefficients are read from device tables indexed by a
     device-side counter, so 50 steps are 50 graph launches with no host work in between.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -210,6 +212,10 @@ class FusedStepRunner:
         self.use_graph = True
         self.table_mode = False
         self.stream = torch.cuda.Stream(device=model.device)
+        # independent network passes of one step run on forked streams inside the captured graph:
+        #   0 serial | 1 appearance || pose, then UNet(cond+uncond batched) | 2 appearance || pose || UNet-uncond, then UNet-cond
+        self.overlap = int(os.environ.get("MD_OVERLAP", "1"))
+        self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
 
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
@@ -236,6 +242,8 @@ class FusedStepRunner:
         self.kv_app = app.context_kv(self._ctx_app)
         self.kv_pose = pose_e.context_kv(self._ctx_app if self._ctx_app.shape[0] in (1, b) else self._ctx_src)
         self.kv_unet = unet.context_kv(self._ctx_unet)
+        self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
+            (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
         key = (b, cch, hh, ww, S, ref.shape[0], tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
                self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
         if key != self.key:
@@ -309,16 +317,47 @@ class FusedStepRunner:
         ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5)
         arena = unet.arena
         arena.reset()
+        main = torch.cuda.current_stream()
+        oc = unet.cfg.out_channels
         if self.table_mode:
             ops.select_row_f32(self.bank_table.view(F32), self.counter, 0, self.bank_cur.view(F32), self.bank_elems // 2)
-            banks = self._bank_views(self.bank_cur)
+        if self.overlap == 0:
+            banks = self._bank_views(self.bank_cur) if self.table_mode else \
+                app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
+            pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
+            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                            only_mid_control=model.only_mid_control)
+            eps_c, eps_u = eps[:b], eps[b:]
         else:
-            banks = app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
-        pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
-        eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                        only_mid_control=model.only_mid_control)
-        oc = unet.cfg.out_channels
-        ops.ddim_update(eps[:b], eps[b:], oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
+            s_app, s_pose, s_uc = self.side
+            eps_u = None
+            if self.table_mode:
+                banks = self._bank_views(self.bank_cur)
+            else:
+                s_app.wait_stream(main)
+                with torch.cuda.stream(s_app):
+                    banks = app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
+            s_pose.wait_stream(main)
+            with torch.cuda.stream(s_pose):
+                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
+            if self.overlap == 2:
+                s_uc.wait_stream(main)
+                with torch.cuda.stream(s_uc):
+                    unet.ws_slot = 1
+                    eps_u = unet.unet(self.x, self.t_cur[:b], self.kv_unet_uc, nread=0)
+                    unet.ws_slot = 0
+            if not self.table_mode:
+                main.wait_stream(s_app)
+            main.wait_stream(s_pose)
+            if self.overlap == 2:
+                eps_c = unet.unet(self.x, self.t_cur[:b], self.kv_unet_uc, banks=banks, pose=pose, nread=b,
+                                  only_mid_control=model.only_mid_control)
+                main.wait_stream(s_uc)
+            else:
+                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                                only_mid_control=model.only_mid_control)
+                eps_c, eps_u = eps[:b], eps[b:]
+        ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
         ops.counter_add(self.counter, 1)
 
     def step(self):

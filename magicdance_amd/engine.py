@@ -142,6 +142,7 @@ class NetEngine:
         self._ctx_cache = None
         self._hint_cache = None
         self._bank_out = None
+        self.ws_slot = 0
         self._write_stop_at = sum(len(st["blocks"]) for st in self._all_st()) if self.kind == "appearance" else -1
 
     # ------------------------------------------------------------------ weight packing
@@ -222,7 +223,13 @@ class NetEngine:
 
     # ------------------------------------------------------------------ small helpers
     def _ws(self):
-        return get_workspace(self.device)
+        """Split-K slabs / GroupNorm partials.  Per engine (and per concurrent pass, ``ws_slot``) so that network
+        passes running on different streams never share scratch."""
+        key = (id(self), self.ws_slot)
+        buf = _WS.get(key)
+        if buf is None:
+            buf = _WS[key] = torch.empty(96 << 20, dtype=torch.uint8, device=self.device)
+        return buf
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
              out_f32=False, out=None):

@@ -137,9 +137,20 @@ def main():
         fam = runner.profile_one_step(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
         ig = fam["igemm"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        # command, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))
+            traffic = pmc.get("igemm_hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one DDIM step)", "achieved": ach,
-                           "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": None,
-                           "launches": ig["launches"], "ms": ig["ms"]}
+                           "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "bytes/launch (PMC, profiles/round1_pmc_summary.json)",
+                           "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
+                           "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
+                           "avg_launch_us": 1e3 * ig["ms"] / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig["ms"]}
         out["families_ms_per_ddim_step"] = {k: {"ms": v["ms"], "launches": v["launches"],
                                                 "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
                                                 "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}

@@ -100,7 +100,7 @@ typedef struct {
   int32_t n1;
   int32_t n1_batches;      /* samples b < n1_batches attend to segment 1; the rest only to segment 0 */
   void* out; int64_t out_batch_stride; int32_t ld_out;       /* fp16 [B][Nq][ld_out] */
-  int32_t batch, heads, nq, d;  /* d in {40, 80, 160} (any multiple of 8 up to 160) */
+  int32_t batch, heads, nq, d;  /* d in 40 / 80 / 160 (SD-1.5) or 8,16,32,64,128 (test geometries) */
   float scale;             /* d^-0.5 */
 } md_attention_params;
 

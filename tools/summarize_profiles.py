@@ -1,0 +1,65 @@
+"""Condense rocprofv3 CSV output (gpurun_out/<dir>) into the small tracked summaries under profiles/.
+usage: python tools/summarize_profiles.py gpurun_out/prof2 profiles/round1"""
+import collections
+import csv
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+LAUNCHES_PER_STEP_IGEMM = 491
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[:90]
+
+
+out = {}
+ks = os.path.join(src, "kt_kernel_stats.csv")
+if os.path.exists(ks):
+    rows = list(csv.DictReader(open(ks)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    ig = [r for r in rows if "igemm_kernel" in r["Name"]]
+    ig_calls = sum(int(r["Calls"]) for r in ig)
+    execs = ig_calls / LAUNCHES_PER_STEP_IGEMM
+    lines = ["# rocprofv3 --kernel-trace --stats : python bench.py --steps 2 --warmup 1 (configs[1], 1 frame, 50 DDIM steps)",
+             f"# total kernel time {tot / 1e6:.1f} ms over {execs:.1f} DDIM-step executions = {tot / 1e6 / execs:.2f} ms/step (profiled run)",
+             "# columns: total_ms, ms_per_ddim_step, calls, avg_us, percent, kernel"]
+    for r in rows[:40]:
+        t = float(r["TotalDurationNs"])
+        lines.append(f"{t / 1e6:10.2f} {t / 1e6 / execs:8.3f} {int(r['Calls']):8d} {float(r['AverageNs']) / 1e3:9.2f} "
+                     f"{float(r['Percentage']):6.2f}  {short(r['Name'])}")
+    open(dst + "_kernel_stats.txt", "w").write("\n".join(lines) + "\n")
+    out["igemm_ms_per_step_profiled"] = sum(float(r["TotalDurationNs"]) for r in ig) / 1e6 / execs
+    out["igemm_avg_launch_us_profiled"] = sum(float(r["TotalDurationNs"]) for r in ig) / 1e3 / ig_calls
+    out["all_kernels_ms_per_step_profiled"] = tot / 1e6 / execs
+for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    p = os.path.join(src, f"{tag}_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(p)):
+        if r["Counter_Name"] != key:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    ig = {k: v for k, v in agg.items() if k.startswith("igemm_kernel")}
+    n = sum(v[0] for v in ig.values())
+    kb = sum(v[1] for v in ig.values())
+    out[f"igemm_{key}_KB_per_launch_raw"] = kb / max(n, 1)
+    out[f"igemm_{key}_launches"] = n
+    lines = [f"# rocprofv3 --pmc {key} : python bench.py --steps 1 --warmup 0 --ddim-steps 4 ; raw counter (KB) per kernel",
+             "# columns: launches, total_KB, avg_KB_per_launch, kernel"]
+    for k, (c, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        lines.append(f"{c:8d} {v:14.1f} {v / c:12.1f}  {k}")
+    open(dst + f"_{tag}.txt", "w").write("\n".join(lines) + "\n")
+if "igemm_FETCH_SIZE_KB_per_launch_raw" in out and "igemm_WRITE_SIZE_KB_per_launch_raw" in out:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 -> double it;
+    # WRITE_SIZE is used as reported (uncalibrated).  Units: KB.
+    out["igemm_hbm_bytes_per_launch"] = (2.0 * out["igemm_FETCH_SIZE_KB_per_launch_raw"] + out["igemm_WRITE_SIZE_KB_per_launch_raw"]) * 1024.0
+    out["note"] = "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB per igemm launch, averaged over all igemm launches of the run"
+json.dump(out, open(dst + "_pmc_summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

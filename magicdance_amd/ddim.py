@@ -214,7 +214,9 @@ class FusedStepRunner:
         self.stream = torch.cuda.Stream(device=model.device)
         # independent network passes of one step run on forked streams inside the captured graph:
         #   0 serial | 1 appearance || pose, then UNet(cond+uncond batched) | 2 appearance || pose || UNet-uncond, then UNet-cond
-        self.overlap = int(os.environ.get("MD_OVERLAP", "1"))
+        #   3 appearance || pose || UNet, the UNet waiting per bank entry (event) and for the pose residuals at its middle block
+        self.overlap = int(os.environ.get("MD_OVERLAP", "3"))
+        self.bank_events = None
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
 
     def _same_rows(self, t):
@@ -321,7 +323,41 @@ class FusedStepRunner:
         oc = unet.cfg.out_channels
         if self.table_mode:
             ops.select_row_f32(self.bank_table.view(F32), self.counter, 0, self.bank_cur.view(F32), self.bank_elems // 2)
-        if self.overlap == 0:
+        if self.overlap == 3:
+            s_app, s_pose, _ = self.side
+            if self.table_mode:
+                banks = self._bank_views(self.bank_cur)
+                unet._bank_events = None
+            else:
+                from .nets import bank_shapes
+                shp = bank_shapes(app.cfg, (int(self.x.shape[2]), int(self.x.shape[3])))
+                if self.bank_events is None or len(self.bank_events) != len(shp):
+                    self.bank_events = [torch.cuda.Event() for _ in shp]
+                # the bank entries are written straight into fixed buffers so the UNet can be enqueued before they exist
+                if getattr(self, "_inline_bank", None) is None or self._inline_bank[0] != (self.ref.shape[0], tuple(shp)):
+                    bufs = [torch.empty((self.ref.shape[0], n, c), dtype=F16, device=self.x.device) for n, c in shp]
+                    from .engine import Act
+                    self._inline_bank = ((self.ref.shape[0], tuple(shp)),
+                                         [Act(t, self.ref.shape[0], 1, t.shape[1], t.shape[2]) for t in bufs])
+                banks = self._inline_bank[1]
+                s_app.wait_stream(main)
+                with torch.cuda.stream(s_app):
+                    app._bank_events = self.bank_events
+                    app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app, bank_out=banks)
+                    app._bank_events = None
+                unet._bank_events = self.bank_events
+            s_pose.wait_stream(main)
+            with torch.cuda.stream(s_pose):
+                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
+            unet._pose_ready = s_pose
+            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                            only_mid_control=model.only_mid_control)
+            unet._bank_events, unet._pose_ready = None, None
+            if not self.table_mode:
+                main.wait_stream(s_app)   # join (the appearance stream ends at its last bank write, already consumed)
+            main.wait_stream(s_pose)
+            eps_c, eps_u = eps[:b], eps[b:]
+        elif self.overlap == 0:
             banks = self._bank_views(self.bank_cur) if self.table_mode else \
                 app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
             pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)

@@ -73,6 +73,7 @@ def get_workspace(device, nbytes=128 << 20):
     key = str(device)
     if key not in _WS or _WS[key].numel() < nbytes:
         _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS[key][:16384].zero_()
     return _WS[key]
 
 
@@ -142,6 +143,8 @@ class NetEngine:
         self._ctx_cache = None
         self._hint_cache = None
         self._bank_out = None
+        self._bank_events = None   # per-bank-entry events when appearance and UNet run on concurrent streams
+        self._pose_ready = None    # (stream to wait on) before the first pose residual is consumed
         self.ws_slot = 0
         self._write_stop_at = sum(len(st["blocks"]) for st in self._all_st()) if self.kind == "appearance" else -1
 
@@ -229,6 +232,7 @@ class NetEngine:
         buf = _WS.get(key)
         if buf is None:
             buf = _WS[key] = torch.empty(96 << 20, dtype=torch.uint8, device=self.device)
+            buf[:16384].zero_()  # split-K arrival counters (md_igemm re-arms them after every use)
         return buf
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
@@ -250,10 +254,18 @@ class NetEngine:
                   out_f32=out_f32, ws=self._ws())
         return Act(out, x.b, hout, wout, nout)
 
+    def _gn_ws(self):
+        """GroupNorm partial sums: a small scratch of its own (the igemm workspace starts with arrival counters)."""
+        key = (id(self), self.ws_slot, "gn")
+        buf = _WS.get(key)
+        if buf is None:
+            buf = _WS[key] = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        return buf
+
     def gn(self, x, gb, *, x1=None, eps=1e-5, silu=True):
         c = x.c + (0 if x1 is None else x1.c)
         out = self.arena.alloc((x.b, x.hw, c), F16)
-        ops.groupnorm(x.t, gb[0], gb[1], out, self._ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
+        ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
                       c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu)
         return Act(out, x.b, x.h, x.w, c)
 
@@ -360,6 +372,8 @@ class NetEngine:
                 dst = None if self._bank_out is None else self._bank_out[len(banks)].t
                 n1 = self.ln(t, blk["ln1"], out=dst)
                 banks.append(n1)                                                   # attention.py:287-292
+                if self._bank_events is not None:  # let a concurrent UNet stream consume this entry right away
+                    self._bank_events[len(banks) - 1].record(torch.cuda.current_stream())
                 if len(banks) == self._write_stop_at:
                     return None  # last bank entry written: the appearance net has no other output (cldm.py:497)
             else:
@@ -373,6 +387,8 @@ class NetEngine:
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
+                if self._bank_events is not None:
+                    torch.cuda.current_stream().wait_event(self._bank_events[bank_idx])
                 bb, nb = bank.b, bank.hw
                 ldvb = (nb + 7) & ~7
                 kr = a.alloc((bb, nb, c), F16)
@@ -495,6 +511,8 @@ class NetEngine:
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
             hs.append(h)
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
+        if self._pose_ready is not None:
+            torch.cuda.current_stream().wait_stream(self._pose_ready)
         if nread > 0 and pose is not None:
             pr = pose.pop()                                                        # cldm.py:93-95
             hh = h.head(nread)

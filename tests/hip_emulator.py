@@ -190,6 +190,17 @@ class _Stream:
     def synchronize(self):
         pass
 
+    def wait_event(self, ev):
+        pass
+
+
+class _Event:
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, stream=None):
+        pass
+
 
 def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
@@ -200,6 +211,7 @@ def install(monkeypatch):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)
     monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     engine._ARENAS.clear()

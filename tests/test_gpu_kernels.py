@@ -77,7 +77,7 @@ def test_igemm_conv(dev, case, cfg):
     if cfg >= 12 and (cin % 64 or cins[0] % 64):
         pytest.skip("buffer-descriptor loader needs 64-channel-aligned sources (the launcher routes these to family 1)")
     out = torch.empty((b, ho * wo, cout), dtype=F16, device=dev)
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride, ups=ups,
               a1=x16[1] if len(cins) > 1 else None, c1=cins[1] if len(cins) > 1 else 0, bias=bias, out=out, ws=ws,
               force_cfg=cfg)
@@ -98,7 +98,7 @@ def test_igemm_splitk_epilogues(dev, splitk):
     ref = F.conv2d(x.half().float(), wt.half().float(), None, padding=1) + bias_b[:, 64:64 + cout, None, None]
     ref = F.silu(ref) + res.half().float()
     out = torch.empty((b, h * w, cout), dtype=F16, device=dev)
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     ops.igemm(_nhwc16(x), engine.pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=3,
               bias=bias_b[:, 64:], bias_batch_stride=256, res=_nhwc16(res), ld_res=cout, act=ops.MD_ACT_SILU, out=out,
               ws=ws, force_splitk=splitk)

@@ -20,7 +20,7 @@ SHAPES = [
 ]
 CFGS = [4, 5, 7, 12, 13, 14, 15, 16, 17, 19]
 SPLITS = [1, 2, 4, 8]
-ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+ws = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
 side = torch.cuda.Stream()
 REPS = 20
 out_f = open(sys.argv[1], "w") if len(sys.argv) > 1 else None

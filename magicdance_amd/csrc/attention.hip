@@ -10,6 +10,7 @@
 // tiles are plain 16-byte copies global -> registers -> LDS, prefetched one tile ahead of the MFMAs.
 // The concat [self ; bank] of the reference (attention.py:305-311) is never materialised: tiles walk segment 0 then 1.
 #include <cstdio>
+#include <cstdlib>
 
 #include "md_common.h"
 
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs g) {
   constexpr int DF = (D + 15) / 16;       // 16-row fragments of O^T
   constexpr int DV = DF * 16;
   constexpr int CPR = DK / 8;             // 16-byte chunks per K row
-  constexpr int KROW = (DK + 8) * 2;      // LDS bytes per K row (padded)
+  constexpr int KROW = (DK + 16) * 2;     // LDS bytes per K row: stride = 32 (mod 64) bytes makes the 16-row ds_read_b128 conflict-free
   constexpr int VROW = 144;               // LDS bytes per V^T row: 64 kv fp16 + 16 pad
   constexpr int KJ = (64 * CPR + 255) / 256;
   constexpr int VJ = (DV * 8 + 255) / 256;
@@ -162,15 +163,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs g) {
           st[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfrag, qf[f][ks], st[f][kf], 0, 0, 0);
       }
     }
-    if (kv0 + 64 > nseg) {  // tail tile of a segment: mask kv >= nseg
+    if (__builtin_amdgcn_readfirstlane(kv0 + 64 - nseg) > 0) {  // tail tile of a segment (wave-uniform, rare): mask kv >= nseg
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kv0 + kf * 16 + lg * 4 + r >= nseg) {
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = kv0 + kf * 16 + lg * 4 + r >= nseg;
 #pragma unroll
-            for (int f = 0; f < QF; ++f) st[f][kf][r] = -INFINITY;
-          }
+          for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
+        }
     }
 
     // ---- online softmax (per query column = per lane, fp32) ---------------------------------------------
@@ -185,7 +186,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs g) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx * g.c);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+      // the running max stops moving after the first few tiles: rescale O / l only when some lane's max grew
+      const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run[f]) != 0;
+      const float alpha = grew ? __builtin_amdgcn_exp2f(m_run[f] - m_new) : 1.0f;
       m_run[f] = m_new;
       float ps = 0.f;
 #pragma unroll
@@ -196,9 +199,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs g) {
           ps += p;
           pf[f][kf >> 1][(kf & 1) * 4 + r] = (half_t)p;
         }
-      l_run[f] = l_run[f] * alpha + ps;
+      if (grew) {
+        l_run[f] *= alpha;
 #pragma unroll
-      for (int i = 0; i < DF; ++i) o[i][f] *= alpha;
+        for (int i = 0; i < DF; ++i) o[i][f] *= alpha;
+      }
+      l_run[f] += ps;
     }
 
     // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
@@ -295,9 +301,17 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
            p->d);
   md::ProfScope prof(MD_FAM_ATTENTION, s, 4.0 * p->batch * p->heads * (double)p->nq * nkv * p->d,
                      2.0 * p->batch * p->heads * p->d * (2.0 * p->nq + 2.0 * nkv), tag);
+  // 128-row query blocks (QF 2) halve the K/V traffic per MFMA but need >= ~2 workgroups per CU to hide the per-tile
+  // latency chain; below that 64-row blocks win (measured: d=80 72->49 us, d=40 B=1 104->94 us, d=40 B=2 unchanged)
+  static const int qf_force = [] {
+    const char* e = getenv("MD_ATTN_QF");
+    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+  }();
+  const long long wg128 = (long long)((p->nq + 127) / 128) * p->heads * p->batch;
+  const int qf = qf_force ? qf_force : (wg128 >= 512 ? 2 : 1);
   switch (p->d) {
-    case 40: return launch<40, 2>(g, s);
-    case 80: return launch<80, 2>(g, s);
+    case 40: return qf == 1 ? launch<40, 1>(g, s) : launch<40, 2>(g, s);
+    case 80: return qf == 1 ? launch<80, 1>(g, s) : launch<80, 2>(g, s);
     case 160: return launch<160, 1>(g, s);
     case 8: return launch<8, 1>(g, s);    // small-geometry test nets (model_channels 64, 8 heads)
     case 16: return launch<16, 1>(g, s);

@@ -8,7 +8,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p "$HERE/build"
 pids=()
 for f in igemm attention norm elementwise runtime; do
-  ( "$HIPCC" $FLAGS ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
+  EXTRA=""
+  # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified file); the softmax touches every S^T / O
+  # element each tile, and the AGPR form cost ~5 v_accvgpr moves per MFMA
+  if [ "$f" = "attention" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+  ( "$HIPCC" $FLAGS $EXTRA ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

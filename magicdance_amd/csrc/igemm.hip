@@ -172,13 +172,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     cc = k_cur - tap * g.cin;
   }
   h8 ra[AJ], rw[WJ];
+  // ---- BUF loader state: per-row byte offsets of the tap-centre pixel (+ this thread's chunk) in either source, relative
+  // to descriptors whose base is shifted back by pad*(win+1) pixels so that every tap offset is >= 0.  Per k-tile the
+  // address of row j is  rowbase[j] (VGPR, constant)  +  soffset (SGPR: tap, channel base)  -> no per-tile address VALU
+  // beyond the validity select (mask bit ? rowbase : OOB).
   [[maybe_unused]] unsigned w_off[WJ];
 #pragma unroll
-  for (int j = 0; j < WJ; ++j) w_off[j] = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u;
+  for (int j = 0; j < WJ; ++j) w_off[j] = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u + (unsigned)gc * 16u;
+  [[maybe_unused]] unsigned rowbase0[AJ], rowbase1[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const unsigned centre = (unsigned)(a_pix[j] + (a_y[j] + g.pad) * g.win + (a_x[j] + g.pad));
+    rowbase0[j] = centre * (unsigned)g.c0 * 2u + (unsigned)gc * 16u;
+    rowbase1[j] = centre * (unsigned)g.c1 * 2u + (unsigned)gc * 16u;
+  }
+  const int shift_pix = ups ? 0 : g.pad * (g.win + 1);
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<half_t*>(g.a0), 0, g.batch * g.hin * g.win * g.c0 * 2, 0x00020000);
+      const_cast<half_t*>(g.a0) - (long long)shift_pix * g.c0, 0, (g.batch * g.hin * g.win + shift_pix) * g.c0 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<half_t*>(g.a1 ? g.a1 : g.a0), 0, g.batch * g.hin * g.win * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
+      const_cast<half_t*>(g.a1 ? g.a1 : g.a0) - (long long)shift_pix * (g.a1 ? g.c1 : g.c0), 0,
+      (g.batch * g.hin * g.win + shift_pix) * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), 0, g.N * g.K * 2, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;  // beyond any tensor: the load returns zeros
 
@@ -197,32 +210,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
       const bool second = cc_u >= g.c0;
       const unsigned cs = second ? g.c1 : g.c0;
-      const unsigned ccc = (unsigned)(second ? cc_u - g.c0 : cc_u) + gc * 8;
+      const unsigned cbase = (unsigned)(second ? cc_u - g.c0 : cc_u);
       const int tapbit = kvalid ? (1 << tap_u) : 0;
       unsigned voff[AJ];
+      unsigned soff = 0;
+      if (ups) {  // nearest x2 upsample: the source pixel is not affine in the tap -> full per-lane offset
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const int sy = (a_y[j] + dy) >> ups, sx = (a_x[j] + dx) >> ups;
-        const unsigned pix = (unsigned)(a_pix[j] + (int)__mul24(sy, g.win) + sx);
-        const unsigned v = (__umul24(pix, cs) + ccc) * 2u;
-        voff[j] = (a_mask[j] & tapbit) ? v : OOB;
+        for (int j = 0; j < AJ; ++j) {
+          const int sy = (a_y[j] + dy) >> 1, sx = (a_x[j] + dx) >> 1;
+          const unsigned pix = (unsigned)(a_pix[j] + (int)__mul24(sy, g.win) + sx);
+          const unsigned v = (__umul24(pix, cs) + cbase + (unsigned)gc * 8u) * 2u;
+          voff[j] = (a_mask[j] & tapbit) ? v : OOB;
+        }
+      } else {
+        soff = ((unsigned)(dy * g.win + dx) * cs + cbase) * 2u;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) voff[j] = (a_mask[j] & tapbit) ? (second ? rowbase1[j] : rowbase0[j]) : OOB;
       }
       if (second) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
-                                                   16, voff[j], 0, 0, 0);
+                                                   16, voff[j], soff, 0, 0);
       } else {
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
-                                                   16, voff[j], 0, 0, 0);
+                                                   16, voff[j], soff, 0, 0);
       }
-      const unsigned kb = kvalid ? (unsigned)(kt_u + gc * 8) * 2u : OOB;
+      const unsigned ksoff = (unsigned)kt_u * 2u;
 #pragma unroll
       for (int j = 0; j < WJ; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
-                                                 16, kvalid ? w_off[j] + kb : OOB, 0, 0, 0);
+                                                 16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
       kt_u += 64;
       cc_u += 64;
       if (g.ksize == 3 && cc_u >= g.cin) {
@@ -422,10 +442,10 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
 
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 // families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
-//           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages
+//           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
 const float kTileEff[4] = {1.00f, 0.85f, 0.85f, 0.70f};
 const int kTileBM[4] = {128, 128, 64, 64}, kTileBN[4] = {128, 64, 128, 64};
-constexpr int kNumFamilies = 5;
+constexpr int kNumFamilies = 6;
 constexpr int kNumCfgs = 4 * kNumFamilies;
 struct TileCfg {
   int bm, bn;
@@ -631,6 +651,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
     case 17: rc = launch_cfg<128, 64, 2, 2, 2, 3>(g, s); break;
     case 18: rc = launch_cfg<64, 128, 2, 2, 2, 3>(g, s); break;
     case 19: rc = launch_cfg<64, 64, 2, 2, 2, 3>(g, s); break;
+    case 20: rc = launch_cfg<128, 128, 2, 2, 2, 4>(g, s); break;
+    case 21: rc = launch_cfg<128, 64, 2, 2, 2, 6>(g, s); break;
+    case 22: rc = launch_cfg<64, 128, 2, 2, 2, 6>(g, s); break;
+    case 23: rc = launch_cfg<64, 64, 2, 2, 2, 6>(g, s); break;
     default: return MD_ERR_BAD_ARG;
   }
   if (rc != MD_OK) return rc;

@@ -246,6 +246,277 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: K / V^T tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, out-of-range = zero fill) into a
+// 2-stage ring: no VGPR staging, no ds_write, one barrier per tile, the next tile in flight under the MFMAs.
+// (A 3-stage ring with counted `s_waitcnt vmcnt(N)` measured no faster and showed rare run-to-run differences inside the
+//  full pipeline -- DMA instructions whose 64 lanes are all out of range (tails, padding rows) apparently may retire ahead
+//  of older loads, which breaks counted waits; the 2-stage form always drains with vmcnt(0).  MAXST = 3 keeps it for study.)
+//   * K tile  : 64 rows x CL 16-byte chunks (CL = 8 / 16 / 32 >= d/8, power of two); a fragment's 16 MFMA rows read the
+//               PERMUTED tile rows  32*(kf>>1) + 8*(i>>2) + 4*(kf&1) + (i&3)  so that the 8 k-slots a lane feeds to the
+//               PV MFMA are 8 CONSECUTIVE kv -> the V^T operand is ONE ds_read_b128 (v1: two ds_read_b64, 2-way conflicts);
+//               chunk c of row r sits at position (c + KM*g(r)) % CL, g(r) = 4*((r>>3)&3) + (r&3): conflict-free b128 reads.
+//   * V^T tile: DV rows x 8 chunks (64 kv), chunk c of row r at (c + r) % 8.
+//   The swizzles are applied to the per-lane SOURCE offset (the LDS image of a DMA is lane-linear).
+//   Per-lane offsets are constants; the tile position is the scalar soffset; tails / padding are out-of-range offsets.
+template <int D, int QF, int MAXST = 2>
+__global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr int KSTEPS = DK / 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);  // LDS chunks per K row
+  constexpr int KM = CL == 8 ? 1 : 2;                       // swizzle multiplier
+  constexpr int KJ = 64 * CL / 256;                         // K DMA instructions per thread per tile
+  constexpr int VJ = (DF * 16 * 8 + 255) / 256;             // V^T DMA instructions per thread per tile
+  constexpr int KBYTES = 64 * CL * 16, VBYTES = VJ * 4096;
+  constexpr int STAGE = KBYTES + VBYTES;
+  constexpr int STAGES = (MAXST >= 3 && 3 * STAGE <= 64 * 1024) ? 3 : 2;
+  constexpr int LPT = KJ + VJ;
+  constexpr int BQ = 64 * QF;
+  constexpr unsigned OOB = 0x80000000u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qbase = blockIdx.x * BQ + wave * (16 * QF);
+
+  h8 qf[QF][KSTEPS];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int row = qbase + f * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int d = ks * 32 + lg * 8;
+      if (row < g.nq && d < D) v = *reinterpret_cast<const h8*>(g.q + b * g.q_bs + (long long)row * g.ld_q + h * D + d);
+      qf[f][ks] = v;
+    }
+  }
+
+  const int t0 = (g.n0 + 63) >> 6;
+  const int t1 = (g.k1 != nullptr && b < g.n1_batches) ? ((g.n1 + 63) >> 6) : 0;
+  const int ntiles = t0 + t1;
+
+  // descriptors (wave-uniform) and per-lane constant source offsets for both segments
+  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.k0 + b * g.k0_bs), 0, g.n0 * g.ld_k0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.vt0 + b * g.vt0_bs), 0, g.heads * D * g.ld_vt0 * 2, 0x00020000);
+  const half_t* k1p = g.k1 ? g.k1 + b * g.k1_bs : g.k0;
+  const half_t* v1p = g.vt1 ? g.vt1 + b * g.vt1_bs : g.vt0;
+  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(k1p), 0, (g.k1 ? g.n1 * g.ld_k1 : 0) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(v1p), 0, (g.vt1 ? g.heads * D * g.ld_vt1 : 0) * 2, 0x00020000);
+  unsigned ko0[KJ], ko1[KJ], vo0[VJ], vo1[VJ];
+  int krow_[KJ], vkv_[VJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const int i = j * 256 + tid;           // LDS chunk index of this lane's DMA slot
+    const int r = i / CL, pos = i % CL;
+    const int gr = 4 * ((r >> 3) & 3) + (r & 3);
+    const int sc = (pos - KM * gr) & (CL - 1);   // source chunk held at this position
+    const bool ok = sc * 8 < D;
+    krow_[j] = r;
+    ko0[j] = ok ? (unsigned)(r * g.ld_k0 + h * D + sc * 8) * 2u : OOB;
+    ko1[j] = ok ? (unsigned)(r * g.ld_k1 + h * D + sc * 8) * 2u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) {
+    const int i = j * 256 + tid;
+    const int r = i >> 3, pos = i & 7;
+    const int sc = (pos - r) & 7;
+    const bool ok = r < D;
+    vkv_[j] = sc * 8;
+    vo0[j] = ok ? (unsigned)((h * D + r) * g.ld_vt0 + sc * 8) * 2u : OOB;
+    vo1[j] = ok ? (unsigned)((h * D + r) * g.ld_vt1 + sc * 8) * 2u : OOB;
+  }
+
+  auto issue_tile = [&](int t, int stage) {
+    char* Ks = smem + stage * STAGE;
+    char* Vs = Ks + KBYTES;
+    const bool live = t < ntiles;
+    const bool s1 = t >= t0;
+    const int kv0 = (s1 ? t - t0 : t) << 6;
+    const int nseg = live ? (s1 ? g.n1 : g.n0) : 0;  // past-the-end tiles fetch zeros (keeps the vmcnt count constant)
+    if (s1) {
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k1) * 2u, vsoff = (unsigned)kv0 * 2u;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk1, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + krow_[j] < nseg) ? ko1[j] : OOB, live ? ksoff : 0u, 0, 0);
+#pragma unroll
+      for (int j = 0; j < VJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv1, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + vkv_[j] < nseg) ? vo1[j] : OOB, live ? vsoff : 0u, 0, 0);
+    } else {
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k0) * 2u, vsoff = (unsigned)kv0 * 2u;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk0, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + krow_[j] < nseg) ? ko0[j] : OOB, live ? ksoff : 0u, 0, 0);
+#pragma unroll
+      for (int j = 0; j < VJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv0, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + vkv_[j] < nseg) ? vo0[j] : OOB, live ? vsoff : 0u, 0, 0);
+    }
+  };
+
+  f4 o[DF][QF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i)
+#pragma unroll
+    for (int f = 0; f < QF; ++f) o[i][f] = f4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QF], l_run[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    m_run[f] = -INFINITY;
+    l_run[f] = 0.f;
+  }
+
+  auto compute_tile = [&](int t, int stage) {
+    const char* Ks = smem + stage * STAGE;
+    const char* Vs = Ks + KBYTES;
+    const bool s1 = t >= t0;
+    const int kv0 = (s1 ? t - t0 : t) << 6;
+    const int nseg = s1 ? g.n1 : g.n0;
+    f4 st[QF][4];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) st[f][kf] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);  // g(row) == lr
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const h8 kfrag = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          st[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfrag, qf[f][ks], st[f][kf], 0, 0, 0);
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane(kv0 + 64 - nseg) > 0) {  // tail tile: mask kv >= nseg
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = kv0 + 32 * (kf >> 1) + 8 * lg + 4 * (kf & 1) + r >= nseg;
+#pragma unroll
+          for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
+        }
+    }
+    h8 pf[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float mx = st[f][0][0];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][kf][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[f], mx * g.c);
+      const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run[f]) != 0;
+      const float alpha = grew ? __builtin_amdgcn_exp2f(m_run[f] - m_new) : 1.0f;
+      m_run[f] = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[f][kf][r] * g.c - m_new);
+          ps += p;
+          pf[f][kf >> 1][(kf & 1) * 4 + r] = (half_t)p;
+        }
+      if (grew) {
+        l_run[f] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DF; ++i) o[i][f] *= alpha;
+      }
+      l_run[f] += ps;
+    }
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int pk = 0; pk < 2; ++pk) {
+        const h8 vfrag = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          o[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf[f][pk], o[i][f], 0, 0, 0);
+      }
+    }
+  };
+
+  if constexpr (STAGES >= 3) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_tile(s, s);
+    int stage = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_tile(t + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
+      compute_tile(t, stage);
+      stage = stage == STAGES - 1 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    issue_tile(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+      // EXPLICIT drain: hipcc does not reliably wait for buffer_load..lds before a barrier (in this kernel it hoisted the
+      // only vmcnt(0) out of the loop -> tiles were read before they landed, rare run-to-run differences)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile t landed for every wave; everyone is done with the other stage
+      if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+      compute_tile(t, t & 1);
+    }
+  }
+
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    float l = l_run[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = qbase + f * 16 + lr;
+    if (row >= g.nq) continue;
+    half_t* op = g.out + b * g.out_bs + (long long)row * g.ld_out + h * D;
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int d = i * 16 + lg * 4;
+      if (d < D) {
+        h4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[i][f][r] * inv);
+        *reinterpret_cast<h4*>(op + d) = ov;
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int D, int QF, int MAXST = 2>
+int launch_v2(const AttnArgs& g, hipStream_t s) {
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
+  constexpr int VJ = (DF * 16 * 8 + 255) / 256;
+  constexpr int STAGE = 64 * CL * 16 + VJ * 4096;
+  constexpr int STAGES = (MAXST >= 3 && 3 * STAGE <= 64 * 1024) ? 3 : 2;
+  constexpr size_t lds = (size_t)STAGES * STAGE;
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v2<D, QF, MAXST>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  constexpr int BQ = 64 * QF;
+  dim3 grid((g.nq + BQ - 1) / BQ, g.heads, g.batch);
+  hipLaunchKernelGGL((attn_kernel_v2<D, QF, MAXST>), grid, dim3(256), lds, s, g);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 template <int D, int QF>
 int launch(const AttnArgs& g, hipStream_t s) {
   constexpr int BQ = 64 * QF;
@@ -309,6 +580,30 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   }();
   const long long wg128 = (long long)((p->nq + 127) / 128) * p->heads * p->batch;
   const int qf = qf_force ? qf_force : (wg128 >= 512 ? 2 : 1);
+  static const int use_v2 = [] {  // MD_ATTN_V=1 selects the register-staged v1 kernels (A/B)
+    const char* e = getenv("MD_ATTN_V");
+    return (e && e[0] == '1') ? 0 : 1;
+  }();
+  // v2 needs 32-bit byte offsets inside each K / V^T operand
+  const bool v2_ok = use_v2 && (long long)p->n0 * p->ld_k0 * 2 < (1LL << 31) && (long long)p->heads * p->d * p->ld_vt0 * 2 < (1LL << 31) &&
+                     (!p->k1 || ((long long)p->n1 * p->ld_k1 * 2 < (1LL << 31) && (long long)p->heads * p->d * p->ld_vt1 * 2 < (1LL << 31)));
+  static const int dbg_mask = [] {  // debug: bit0 = v2 for self/bank attention, bit1 = v2 for cross attention, bit2 = 3-stage ring for d=40
+    const char* e = getenv("MD_ATTN_V2_MASK");
+    return e ? atoi(e) : 3;
+  }();
+  const bool is_cross = p->n0 != p->nq;
+  if (v2_ok && (dbg_mask & (is_cross ? 2 : 1))) {
+    if ((dbg_mask & 4) && p->d == 40) return qf == 1 ? launch_v2<40, 1, 3>(g, s) : launch_v2<40, 2, 3>(g, s);  // bit2: 3-stage ring
+    switch (p->d) {
+      case 40: return qf == 1 ? launch_v2<40, 1>(g, s) : launch_v2<40, 2>(g, s);
+      case 80: return qf == 1 ? launch_v2<80, 1>(g, s) : launch_v2<80, 2>(g, s);
+      case 160: return launch_v2<160, 1>(g, s);
+      case 32: return launch_v2<32, 1>(g, s);
+      case 64: return qf == 1 ? launch_v2<64, 1>(g, s) : launch_v2<64, 2>(g, s);
+      case 128: return launch_v2<128, 1>(g, s);
+      default: break;  // 8 / 16: v1
+    }
+  }
   switch (p->d) {
     case 40: return qf == 1 ? launch<40, 1>(g, s) : launch<40, 2>(g, s);
     case 80: return qf == 1 ? launch<80, 1>(g, s) : launch<80, 2>(g, s);

@@ -97,7 +97,8 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 // (a0, a1, w), per-lane 32-bit byte offsets built from 24-bit multiplies, and "out of image / past K" expressed as an
 // out-of-range offset, which the hardware turns into zeros in LDS.  (The k-tile loop was VALU-bound on address
 // generation with the pointer forms: ~900 VALU cycles vs ~540 MFMA cycles per 128x128x64 tile.)
-// STAGES > 2 (GLDS only): software pipeline with STAGES-1 k-tiles of LDS-DMA in flight.  A k-tile iteration is
+// STAGES > 2 (GLDS only; NOT used by the tuned table / defaults: counted vmcnt proved unreliable next to DMA instructions
+// whose lanes are all out of range -- see attention.hip -- and bought < 3 %): software pipeline with STAGES-1 k-tiles of LDS-DMA in flight.  A k-tile iteration is
 // latency-bound otherwise (~1.2 us per 64-deep tile measured with one tile of prefetch, vs ~0.1-0.2 us of MFMA work), so
 // the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
 //   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       const int stage = (kt - kt_begin) & 1;
       const bool more = kt + 1 < kt_end;
       if constexpr (GLDS) {
-        __syncthreads();  // tile kt has landed (vmcnt(0) precedes the barrier); every wave is done with stage^1
+        // explicit drain of this wave's LDS-DMA: the compiler's own wait before a barrier is not reliable for
+        // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt has landed for every wave; every wave is done with stage^1
         if (more) fetch_tile(stage ^ 1);
       } else {
         if (more) fetch_tile(stage ^ 1);

@@ -11,6 +11,8 @@ Topology / arithmetic follow the reference (paths relative to model_lib/ControlN
   SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU   ldm/modules/attention.py:366-385, 278-320, 168-199, 50-77
 There is no CPU path: every op raises if libmagicdance_hip.so is missing.
 """
+import os
+
 import torch
 
 from . import ops
@@ -18,6 +20,19 @@ from .ops import MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU
 
 F16, F32 = torch.float16, torch.float32
 _ES = {torch.float16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1}
+_POISON = os.environ.get("MD_ARENA_POISON", "0") == "1"     # debug: NaN-fill the arena at every reset
+_CHECK = os.environ.get("MD_DEBUG_FINITE", "0") == "1"      # debug: synchronous finiteness check after every op
+
+
+_TRACE = None  # debug: list collecting (op description, checksum) when set (tools/trace_diff.py)
+
+
+def _chk(t, what):
+    if _TRACE is not None:
+        _TRACE.append((what, float(t.double().abs().sum()), float(t.double().sum())))
+    if _CHECK and not bool(torch.isfinite(t.float()).all()):
+        raise FloatingPointError(f"non-finite output of {what} shape {tuple(t.shape)}")
+    return t
 
 
 # ----------------------------------------------------------------------------------------------- arena
@@ -32,6 +47,9 @@ class Arena:
 
     def reset(self):
         self.cur, self.off = 0, 0
+        if _POISON and not self.frozen:
+            for blk in self.blocks:  # debug: any read of memory a kernel did not write this pass shows up as NaN
+                blk.fill_(0xFF)
 
     def alloc(self, shape, dtype=F16, zero=False):
         n = 1
@@ -252,6 +270,7 @@ class NetEngine:
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
                   out_f32=out_f32, ws=self._ws())
+        _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
         return Act(out, x.b, hout, wout, nout)
 
     def _gn_ws(self):
@@ -267,12 +286,14 @@ class NetEngine:
         out = self.arena.alloc((x.b, x.hw, c), F16)
         ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
                       c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu)
+        _chk(out, f"groupnorm c={c} hw={x.hw} b={x.b}")
         return Act(out, x.b, x.h, x.w, c)
 
     def ln(self, x, gb, out=None):
         if out is None:
             out = self.arena.alloc((x.b, x.hw, x.c), F16)
         ops.layernorm(x.t, gb[0], gb[1], out, x.b * x.hw, x.c)
+        _chk(out, f"layernorm c={x.c} rows={x.b * x.hw}")
         return Act(out, x.b, x.h, x.w, x.c)
 
     # ------------------------------------------------------------------ embeddings
@@ -357,6 +378,7 @@ class NetEngine:
             kw = dict(k1=k1, vt1=vt1, n1=n1, ld_k1=ld_k1, ld_vt1=ld_vt1, k1_bs=k1_bs, vt1_bs=vt1_bs, n1_batches=n1_batches)
         ops.attention(q, k0, vt0, out, batch=b, heads=heads, nq=nq, d=dh, n0=n0, ld_q=ld_q, ld_k0=ld_k0, ld_vt0=ld_vt0,
                       ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, **kw)
+        _chk(out, f"attention b={b} nq={nq} n0={n0} d={dh} seg1={None if seg1 is None else seg1[4]}")
         return out
 
     def transformer(self, st, x, ctx_kv, ctx_idx, mode, banks, bank_idx, nread):

@@ -16,6 +16,11 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+# When a list, every md_igemm / md_attention call appends (launcher, params, flops, keepalive) so that bench.py can replay
+# exactly the launches of one DDIM step in a captured graph and time a kernel family with HIP events on its own stream.
+RECORD = None
+
+
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0):
@@ -34,6 +39,9 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
     p.force_cfg, p.force_splitk = force_cfg, force_splitk
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
+    if RECORD is not None:
+        m = batch * hout * wout
+        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws)))
     return out
 
 
@@ -51,6 +59,9 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
     p.batch, p.heads, p.nq, p.d = batch, heads, nq, d
     p.scale = float(d) ** -0.5 if scale is None else scale
     _lib.check(lib.md_attention(C.byref(p), stream_ptr()), "md_attention")
+    if RECORD is not None:
+        nb1 = min(n1_batches, batch) if k1 is not None else 0
+        RECORD.append(("attention", lib.md_attention, p, 4.0 * heads * nq * d * (batch * n0 + nb1 * n1), (q, k0, vt0, k1, vt1, out)))
     return out
 
 

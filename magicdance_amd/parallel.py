@@ -73,15 +73,43 @@ class FrameShardedSampler:
         st = model._fused
         if st is None:
             st = model._fused = FusedStepRunner(model)
+        import ctypes as C
         from . import ops
         with torch.cuda.stream(st.stream):
             st.prepare(c, x_T, sampler, scale, table_mode=False)
             st._launch_sequence()          # sizes the arena / warms caches
             st.stream.synchronize()
             st.counter.zero_()
-            ops.prof_enable(True)
+            ops.prof_enable(True)          # (a) per-launch events, un-captured: includes the eager launch latency
+            ops.RECORD = []
             st._launch_sequence()
             st.stream.synchronize()
             fam = ops.prof_collect()
             ops.prof_enable(False)
+            rec, ops.RECORD = ops.RECORD, None
+            # (b) the same launches of one family replayed back-to-back from a captured graph on this stream, bracketed
+            #     by HIP events: average launch duration as the GPU sees it inside the step graph
+            sp = ops.stream_ptr()
+            for name in ("igemm", "attention"):
+                calls = [r for r in rec if r[0] == name]
+                if not calls:
+                    continue
+                g = ops.Graph()
+                g.begin()
+                for _, fn, p, _, _ in calls:
+                    fn(C.byref(p), sp)
+                g.end()
+                g.launch()
+                st.stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 3
+                e0.record(st.stream)
+                for _ in range(reps):
+                    g.launch()
+                e1.record(st.stream)
+                st.stream.synchronize()
+                g.destroy()
+                fam[name]["graph_ms"] = e0.elapsed_time(e1) / reps
+                fam[name]["graph_launches"] = len(calls)
+                fam[name]["graph_flops"] = float(sum(r[3] for r in calls))
         return fam

@@ -48,14 +48,19 @@ torch.cuda.empty_cache()
 F16 = torch.float16
 side = torch.cuda.Stream()
 ws = torch.zeros(512 << 20, dtype=torch.uint8, device=dev)
-REPS = 10
+REPS = 12
+SPLIT_MARGIN = float(os.environ.get("SPLIT_MARGIN", "0.15"))
 lines, total_best, total_default = [], 0.0, 0.0
 for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     M, N, K, ks, st, up, B, h, w, c0, c1, act = key
     ho, wo = (2 * h, 2 * w) if up else (((h + 1) // 2, (w + 1) // 2) if st == 2 else (h, w))
     x0 = torch.randn(B, h * w, c0, device=dev).to(F16)
     x1 = torch.randn(B, h * w, c1, device=dev).to(F16) if c1 else None
-    wt = (torch.randn(N, K, device=dev) * 0.02).to(F16)
+    # cold-cache weights: in the real step every layer streams its own weights from HBM (4.2 GB per step, far beyond the
+    # 256 MB Infinity Cache), so each replayed launch reads a different copy (>= 320 MB of copies in rotation)
+    ncopy = max(2, min(REPS, int((320 << 20) // max(1, N * K * 2)) + 1))
+    wts = [(torch.randn(N, K, device=dev) * 0.02).to(F16) for _ in range(ncopy)]
+    wt = wts[0]
     bias = torch.randn(N, device=dev)
     nout = N // 2 if act == 2 else N
     out = torch.empty(B, ho * wo, nout, dtype=F16, device=dev)
@@ -66,8 +71,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     res = []
     for cfg in cfgs:
         for sp in splits:
-            def run():
-                ops.igemm(x0, wt, N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
+            def run(i=0):
+                ops.igemm(x0, wts[i % ncopy], N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
                           bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp)
             try:
                 with torch.cuda.stream(side):
@@ -75,8 +80,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
                     side.synchronize()
                     g = ops.Graph()
                     g.begin()
-                    for _ in range(REPS):
-                        run()
+                    for i in range(REPS):
+                        run(i)
                     g.end()
                     g.launch()
                     side.synchronize()
@@ -91,6 +96,12 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
             except Exception as ex:  # noqa: BLE001
                 print("ERR", key, cfg, sp, ex, flush=True)
     res.sort()
+    # split-K costs a second launch slot and slab traffic that the isolated timing under-prices when three network streams
+    # share the GPU: take a split config only when it beats the best unsplit one by > SPLIT_MARGIN
+    best_unsplit = min((r for r in res if r[2] == 1), default=None)
+    if best_unsplit is not None and res[0][2] > 1 and res[0][0] > (1.0 - SPLIT_MARGIN) * best_unsplit[0]:
+        res.remove(best_unsplit)
+        res.insert(0, best_unsplit)
     us, cfg, sp = res[0]
     total_best += us * count
     lines.append(f"    {{{M}, {N}, {K}, {ks}, {st}, {up}, {cfg}, {sp}}},  // x{count} {us:.1f}us {2.0 * M * N * K / us / 1e6:.0f}TF (B={B} {h}x{w} c={c0}+{c1})")

@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=1)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--size", type=int, default=64, help="latent side (64 = 512x512)")
+    ap.add_argument("--sequence", type=int, default=0,
+                    help="non-default workload: a pose sequence of this many frames per GPU sharing one reference image "
+                         "(bank table computed once per sequence), sampled in batches of --frames-per-gpu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -111,7 +114,13 @@ def main():
     my = slice(rank * fpg, (rank + 1) * fpg)
     pose, ctx, ref, x_T = inp["pose"][my].contiguous(), inp["ctx"], inp["ref"], inp["x_T"].repeat(fpg, 1, 1, 1)
 
+    if args.sequence:
+        inp = synthetic.synth_inputs((args.size, args.size), frames=args.sequence * world, seed=0, device=dev)
+        seq_pose = inp["pose"][rank * args.sequence:(rank + 1) * args.sequence].contiguous()
+
     def one_batch():
+        if args.sequence:
+            return runner.sample_sequence(seq_pose, ctx, ref, inp["x_T"], frames_per_batch=fpg, ddim_steps=args.ddim_steps, scale=7.0)
         return runner.sample(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
 
     for _ in range(args.warmup):
@@ -131,12 +140,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert bool(torch.isfinite(z).all()), "non-finite latents"
-    frames = args.steps * fpg * world
+    frames = args.steps * (args.sequence if args.sequence else fpg) * world
     out = {"metric": "512x512 frames/sec @ 50 DDIM steps", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
            "ms_per_ddim_step": 1e3 * dt / args.steps / args.ddim_steps,
-           "config": {"workload": f"configs[1]: {fpg} frame(s)/GPU {8 * args.size}x{8 * args.size}, {args.ddim_steps}-step DDIM, "
+           "config": {"workload": (f"sequence of {args.sequence} frames/GPU sharing one reference (bank table once per sequence), "
+                                   f"batches of {fpg}, " if args.sequence else f"configs[1]: {fpg} frame(s)/GPU ") +
+                                  f"{8 * args.size}x{8 * args.size}, {args.ddim_steps}-step DDIM, "
                                   "appearance + pose ControlNet + UNet cond/uncond, CFG 7, latents in -> latents out",
                       "frames_per_gpu": fpg, "ddim_steps": args.ddim_steps, "weights": "seeded synthetic, SD-1.5 geometry",
                       "parallelism": f"frame-shard x{world}"}}

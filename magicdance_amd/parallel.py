@@ -64,6 +64,45 @@ class FrameShardedSampler:
         return z
 
     @torch.no_grad()
+    def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0):
+        """A whole pose sequence sharing one reference image (the entry points' use case, test_any_image_pose.py:201-262:
+        same ref latent, same text, same x_T for every frame).  With ``wonoise`` the appearance bank depends on the DDIM
+        step only, so the S banks are computed ONCE per sequence (round-robin over ranks + RCCL broadcast when world > 1)
+        and every batch of ``frames_per_batch`` frames replays the captured step graph in table mode.
+        pose_frames [F,3,8h,8w] = this rank's frames; x_T [1,4,h,w].  Returns this rank's latents [F,4,h,w]."""
+        model = self.model
+        sampler = DDIMSampler_ReferenceOnly(model)
+        sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
+        st = model._fused
+        if st is None:
+            st = model._fused = FusedStepRunner(model)
+        F = pose_frames.shape[0]
+        outs = []
+        caller = torch.cuda.current_stream()
+        st.stream.wait_stream(caller)
+        with torch.cuda.stream(st.stream):
+            have_table = False
+            for f0 in range(0, F, frames_per_batch):
+                pose = pose_frames[f0:f0 + frames_per_batch].contiguous()
+                b = pose.shape[0]
+                c, _ = self._cond(pose, ctx, ref)
+                old_key = st.key
+                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True)
+                if not have_table or st.key != old_key:   # (re)allocated buffers: the table must be filled for this geometry
+                    S = st.S
+                    st.compute_bank_rows([i for i in range(S) if i % self.world == self.rank])
+                    if self.world > 1:
+                        import torch.distributed as dist
+                        for i in range(S):
+                            dist.broadcast(st.bank_table[i], src=i % self.world, group=self.group)
+                    have_table = True
+                for _ in range(st.S):
+                    st.step()
+                outs.append(st.x.clone())
+        caller.wait_stream(st.stream)
+        return torch.cat(outs, 0)
+
+    @torch.no_grad()
     def profile_one_step(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0):
         """Run ONE DDIM step as plain (un-captured) launches so md_prof_* can time every kernel."""
         model = self.model

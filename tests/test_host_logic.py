@@ -71,3 +71,43 @@ def test_product_refuses_cpu_and_missing_extension(monkeypatch):
     with pytest.raises(_lib.MagicDanceHipError, match="no CPU/PyTorch fallback"):
         _lib.load()
     assert M.__version__
+
+
+def test_sequence_sampling_reuses_bank_table(monkeypatch):
+    """parallel.FrameShardedSampler.sample_sequence (bank table computed once, frames in batches) == one big batch."""
+    hip_emulator.install(monkeypatch)
+    from magicdance_amd import ddim, parallel, synthetic
+    orig_init = ddim.FusedStepRunner.__init__
+
+    def init(self, model):
+        orig_init(self, model)
+        self.use_graph = False
+    monkeypatch.setattr(ddim.FusedStepRunner, "__init__", init)
+    model = H.build_hip_model(64, 2, seed=0, device="cpu", image_size=8)
+    inp = synthetic.synth_inputs((8, 8), frames=3, seed=1)
+    r = parallel.FrameShardedSampler(model)
+    z_seq = r.sample_sequence(inp["pose"], inp["ctx"], inp["ref"], inp["x_T"], frames_per_batch=2, ddim_steps=4)
+    model._fused = None
+    z_ref = r.sample(inp["pose"], inp["ctx"], inp["ref"], inp["x_T"].repeat(3, 1, 1, 1), ddim_steps=4)
+    assert z_seq.shape == z_ref.shape == (3, 4, 8, 8)
+    assert _rel(z_seq.numpy(), z_ref.numpy()) <= 6e-3   # emulated convs differ per batch size; on the GPU this is exact
+
+
+def test_entry_point_cli_and_preprocessing(tmp_path):
+    """the reference shell wrapper's flag set parses unchanged; image preprocessing = centred square crop + 512 resize."""
+    from PIL import Image
+    from magicdance_amd import entry
+    argv = ("--model_config model_lib/ControlNet/models/cldm_v15_reference_only_pose.yaml --num_train_steps 1 --img_bin_limit all "
+            "--train_batch_size 1 --use_fp16 --control_mode controlnet_important --control_type body+hand+face "
+            "--train_dataset tiktok_video_arnold --v4 --with_text --wonoise --local_image_dir ./out --local_log_dir ./log "
+            "--image_pretrain_dir ./pretrained_weights/model_state-110000.th --local_pose_path ./poses "
+            "--local_cond_image_path ./ref.png").split()
+    a = entry.build_parser().parse_args(argv)
+    assert a.control_mode == "controlnet_important" and a.wonoise and a.use_fp16 and a.ddim_steps == 50 and a.eta == 0.0
+    img = Image.fromarray((np.random.RandomState(0).rand(300, 400, 3) * 255).astype(np.uint8))
+    p = str(tmp_path / "x.png")
+    img.save(p)
+    t = entry._load_square_512(p, normalize=False)
+    assert tuple(t.shape) == (3, 512, 512) and 0.0 <= float(t.min()) and float(t.max()) <= 1.0
+    n = entry._load_square_512(p, normalize=True)
+    assert abs(float(n.mean()) - (float(t.mean()) - 0.5) / 0.5) < 1e-5

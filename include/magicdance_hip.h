@@ -149,6 +149,11 @@ int md_gemv_f32(const float* x, const void* w, const float* bias, float* y, int3
 /* rows of a table -> fixed "current step" buffer: dst[i] = table[row*width + i]  (fp32) */
 int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, float* dst,
                       int32_t width, void* stream);
+/* Multi-segment row gather (the per-step pick of the reference-KV table, SURVEY 8(e) collective 1): for every segment
+ * s, dst[dst_off_s ..+len_s) = table[tab_off_s + row*len_s ..+len_s), row = *row_counter + row_offset.
+ * seg: device int64 [nseg][3] = (tab_off, len, dst_off), all in 16-byte units; max_row_units = max len. */
+int md_gather_rows(const void* table, const int64_t* seg, int32_t nseg, int64_t max_row_units,
+                   const int32_t* row_counter, int32_t row_offset, void* dst, void* stream);
 /* increments *counter by 1 (device side), used to advance the DDIM step inside a captured graph */
 int md_counter_add(int32_t* counter, int32_t delta, void* stream);
 

@@ -104,6 +104,18 @@ __global__ void select_row_f32(const float* __restrict__ table, const int* __res
   dst[i] = table[(long long)row * width + i];
 }
 
+// one blockIdx.y per segment; seg = (table offset, row length, dst offset) in 16-byte units
+__global__ __launch_bounds__(256) void gather_rows(const uint4* __restrict__ table, const long long* __restrict__ seg,
+                                                   const int* __restrict__ counter, int row_offset,
+                                                   uint4* __restrict__ dst) {
+  const long long* sg = seg + 3 * blockIdx.y;
+  const long long len = sg[1];
+  const int row = (counter ? *counter : 0) + row_offset;
+  const uint4* src = table + sg[0] + (long long)row * len;
+  uint4* d = dst + sg[2];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long long)gridDim.x * 256) d[i] = src[i];
+}
+
 __global__ void counter_add(int* counter, int delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *counter += delta;
 }
@@ -206,6 +218,19 @@ extern "C" int md_select_row_f32(const float* table, const int32_t* row_counter,
   md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)width * 8.0);
   hipLaunchKernelGGL(select_row_f32, dim3((width + 255) / 256), dim3(256), 0, s, table, row_counter, row_offset, dst,
                      width);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_gather_rows(const void* table, const int64_t* seg, int32_t nseg, int64_t max_row_units,
+                              const int32_t* row_counter, int32_t row_offset, void* dst, void* stream) {
+  if (!table || !seg || !dst || nseg <= 0 || max_row_units <= 0) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, 0.0);
+  long long gx = (max_row_units + 1023) / 1024;  // ~4 units per thread
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(gather_rows, dim3((unsigned)gx, (unsigned)nseg), dim3(256), 0, s, (const uint4*)table,
+                     (const long long*)seg, row_counter, row_offset, (uint4*)dst);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }

@@ -177,7 +177,10 @@ class DDIMSampler_ReferenceOnly(object):
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            st.prepare(c, img, self, scale)
+            table = os.environ.get("MD_BANK_MODE", "table") != "inline"
+            st.prepare(c, img, self, scale, table_mode=table)
+            if table:
+                st.compute_bank_rows(range(total))
             for i in range(total):
                 st.step()
                 index = total - i - 1
@@ -198,11 +201,16 @@ class FusedStepRunner:
     sample_log calls while shapes / context / step count stay the same).
 
     bank modes:
-      inline : the appearance net runs inside every step graph (single call, nothing amortised)
-      table  : the banks of all S steps live in ``bank_table`` [S, bank_elems] (they depend on (ref, t, ctx) only,
-               never on the frame); the step graph copies row ``counter`` into ``bank_cur`` and skips the appearance
-               net.  Used for multi-GPU frame sharding (rows computed round-robin across ranks and broadcast over
-               RCCL, magicdance_amd/parallel.py) and for multi-frame sequences sharing one reference image.
+      inline : the appearance net runs inside every step graph on a forked stream (MD_BANK_MODE=inline; also what the
+               generic per-call route does)
+      table  : (default) with ``wonoise`` the bank depends on (ref, t, ctx) only, never on the frame or on x_t, so the
+               banks of all S steps are computed BEFORE the loop: the appearance net runs on batches of ``bank_chunk``
+               timesteps at once (big, MFMA-efficient launches instead of S batch-1 passes) and the UNet's own to_k / to_v
+               of every bank entry are applied there too.  ``bank_table`` holds, per bank entry, K [S, bref, n, c] and
+               V^T [S, bref, c, ldv] (46 MB fp16 per step at 512x512, 2.3 GB for 50 steps); the step graph gathers row
+               ``counter`` into ``bank_cur`` with one md_gather_rows launch and skips the appearance net and the bank
+               projections.  The same table serves multi-GPU frame sharding (row blocks computed per rank and exchanged
+               with RCCL broadcasts, magicdance_amd/parallel.py) and multi-frame sequences sharing one reference image.
     """
 
     def __init__(self, model):
@@ -217,6 +225,7 @@ class FusedStepRunner:
         #   3 appearance || pose || UNet, the UNet waiting per bank entry (event) and for the pose residuals at its middle block
         self.overlap = int(os.environ.get("MD_OVERLAP", "3"))
         self.bank_events = None
+        self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
 
     def _same_rows(self, t):
@@ -288,27 +297,62 @@ class FusedStepRunner:
         self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.bank_table = self.bank_cur = None
         if table_mode:
+            from .engine import BankKV
             app = self.model.engines()[0]
-            self.bank_geo, off = [], 0
+            self.bank_geo, segs, toff, coff = [], [], 0, 0
             for n, c in bank_shapes(app.cfg, (hh, ww)):
-                self.bank_geo.append((off, bref, n, c))
-                off += bref * n * c
-            self.bank_elems = (off + 63) & ~63
-            self.bank_table = torch.empty((S, self.bank_elems), dtype=F16, device=dev)
-            self.bank_cur = torch.empty((self.bank_elems,), dtype=F16, device=dev)
+                ldv = (n + 7) & ~7
+                lk, lv = bref * n * c, bref * c * ldv
+                self.bank_geo.append((toff, toff + S * lk, coff, coff + lk, n, c, ldv))
+                segs += [(toff // 8, lk // 8, coff // 8), ((toff + S * lk) // 8, lv // 8, (coff + lk) // 8)]
+                toff += S * (lk + lv)
+                coff += lk + lv
+            self.bank_table = torch.zeros((toff,), dtype=F16, device=dev)   # zeros: the V^T pad columns stay zero
+            self.bank_cur = torch.zeros((coff,), dtype=F16, device=dev)
+            self.bank_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
+            self.bank_seg_max = max(sg[1] for sg in segs)
+            self.bank_cur_kv = [BankKV(self.bank_cur[ck:ck + bref * n * c].view(bref, n, c),
+                                       self.bank_cur[cv:cv + bref * c * ldv].view(bref, c, ldv), bref, n, c, ldv)
+                                for (_, _, ck, cv, n, c, ldv) in self.bank_geo]
+            self._bank_tmp = None
 
-    def _bank_views(self, flat):
-        from .engine import Act
-        return [Act(flat[off:off + bb * n * c].view(bb, n, c), bb, 1, n, c) for off, bb, n, c in self.bank_geo]
+    def table_slabs(self, r0, r1):
+        """The contiguous pieces of ``bank_table`` that hold DDIM rows [r0, r1) (two per bank entry: K and V^T)."""
+        bref, out = self.ref.shape[0], []
+        for tk, tv, _, _, n, c, ldv in self.bank_geo:
+            lk, lv = bref * n * c, bref * c * ldv
+            out += [self.bank_table[tk + r0 * lk:tk + r1 * lk], self.bank_table[tv + r0 * lv:tv + r1 * lv]]
+        return out
 
     def compute_bank_rows(self, rows):
-        """Run the appearance net for DDIM steps ``rows`` (indices into the flipped timestep order) and store each
-        step's 16 bank tensors in ``bank_table[row]``."""
-        app = self.model.engines()[0]
-        for r in rows:
+        """Fill the reference-KV table for DDIM steps ``rows`` (indices into the flipped timestep order): the appearance
+        net runs on ``bank_chunk`` timesteps per pass (sample = (step, ref) pair, per-sample time embedding), then the
+        UNet's to_k / to_v project each of the 16 bank tensors for the whole chunk straight into the table."""
+        from .engine import Act
+        app, _, unet = self.model.engines()
+        rows = list(rows)
+        bref = self.ref.shape[0]
+        per = max(1, self.bank_chunk // bref)
+        i = 0
+        while i < len(rows):
+            j = i + 1
+            while j < len(rows) and j - i < per and rows[j] == rows[j - 1] + 1:
+                j += 1
+            r0, tc = rows[i], j - i
+            i = j
+            nb = tc * bref
+            if self._bank_tmp is None or self._bank_tmp[0] < nb:
+                self._bank_tmp = (per * bref, [torch.empty((per * bref, n, c), dtype=F16, device=self.x.device)
+                                               for (_, _, _, _, n, c, _) in self.bank_geo])
+            tmp = [Act(t[:nb], nb, 1, t.shape[1], t.shape[2]) for t in self._bank_tmp[1]]
             app.arena.reset()
-            t_dev = self.ts_table[r, :self.ref.shape[0]].contiguous()
-            app.appearance(self.ref, t_dev, self.kv_app, bank_out=self._bank_views(self.bank_table[r]))
+            t_dev = self.ts_table[r0:r0 + tc, 0].repeat_interleave(bref).contiguous()
+            x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
+            app.appearance(x, t_dev, self.kv_app, bank_out=tmp)
+            for e, (tk, tv, _, _, n, c, ldv) in enumerate(self.bank_geo):
+                lk, lv = bref * n * c, bref * c * ldv
+                unet.project_bank(e, tmp[e], self.bank_table[tk + r0 * lk:tk + (r0 + tc) * lk].view(nb, n, c),
+                                  self.bank_table[tv + r0 * lv:tv + (r0 + tc) * lv].view(nb, c, ldv))
 
     def _launch_sequence(self):
         """One DDIM step as a fixed launch sequence on fixed addresses."""
@@ -322,11 +366,12 @@ class FusedStepRunner:
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
         if self.table_mode:
-            ops.select_row_f32(self.bank_table.view(F32), self.counter, 0, self.bank_cur.view(F32), self.bank_elems // 2)
+            ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
+                            self.bank_cur)
         if self.overlap == 3:
             s_app, s_pose, _ = self.side
             if self.table_mode:
-                banks = self._bank_views(self.bank_cur)
+                banks = self.bank_cur_kv
                 unet._bank_events = None
             else:
                 from .nets import bank_shapes
@@ -358,7 +403,7 @@ class FusedStepRunner:
             main.wait_stream(s_pose)
             eps_c, eps_u = eps[:b], eps[b:]
         elif self.overlap == 0:
-            banks = self._bank_views(self.bank_cur) if self.table_mode else \
+            banks = self.bank_cur_kv if self.table_mode else \
                 app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
             pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
             eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
@@ -368,7 +413,7 @@ class FusedStepRunner:
             s_app, s_pose, s_uc = self.side
             eps_u = None
             if self.table_mode:
-                banks = self._bank_views(self.bank_cur)
+                banks = self.bank_cur_kv
             else:
                 s_app.wait_stream(main)
                 with torch.cuda.stream(s_app):

@@ -141,6 +141,15 @@ class Act:
         return Act(self.t[:nb], nb, self.h, self.w, self.c)
 
 
+class BankKV:
+    """One bank entry already projected by the UNet's own to_k / to_v (attention.py:303-311 computes
+    to_k(cat[x, bank]), linear in the tokens): K [b, n, c] and V^T [b, c, ldv] fp16, the form md_attention's second
+    segment consumes.  Rows of the per-sequence reference-KV table."""
+
+    def __init__(self, k, vt, b, n, c, ldv):
+        self.k, self.vt, self.b, self.hw, self.c, self.ldv = k, vt, b, n, c, ldv
+
+
 def _require_gpu(device):
     """The hot path exists only as HIP kernels: refuse any other device and any missing extension, loudly."""
     if device.type != "cuda":
@@ -161,6 +170,7 @@ class NetEngine:
         self._ctx_cache = None
         self._hint_cache = None
         self._bank_out = None
+        self._bank_blocks = None
         self._bank_events = None   # per-bank-entry events when appearance and UNet run on concurrent streams
         self._pose_ready = None    # (stream to wait on) before the first pose residual is consumed
         self.ws_slot = 0
@@ -413,10 +423,12 @@ class NetEngine:
                     torch.cuda.current_stream().wait_event(self._bank_events[bank_idx])
                 bb, nb = bank.b, bank.hw
                 ldvb = (nb + 7) & ~7
-                kr = a.alloc((bb, nb, c), F16)
-                vtr = a.alloc((bb, c, ldvb), F16, zero=(ldvb != nb))
-                ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=kr,
-                          ld_out=c, out_t=vtr, n_tr_begin=c, ld_t=ldvb, ws=self._ws())
+                if isinstance(bank, BankKV):
+                    kr, vtr = bank.k, bank.vt
+                else:
+                    kr = a.alloc((bb, nb, c), F16)
+                    vtr = a.alloc((bb, c, ldvb), F16, zero=(ldvb != nb))
+                    self._project_bank(blk, bank, kr, vtr)
                 if bb == 1:
                     seg1 = (kr, c, vtr, ldvb, nb, 0, 0)
                 else:
@@ -441,6 +453,18 @@ class NetEngine:
             t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c))
         t = Act(t.t, b, x.h, x.w, c)
         return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x)
+
+    def _project_bank(self, blk, bank, k_out, vt_out):
+        bb, nb, c = bank.b, bank.hw, bank.c
+        ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
+                  out_t=vt_out, n_tr_begin=c, ld_t=(nb + 7) & ~7, ws=self._ws())
+
+    def project_bank(self, e, bank, k_out, vt_out):
+        """K / V^T of bank entry ``e`` (read order = _all_st order, one transformer block each in SD-1.5) for a whole
+        batch of bank rows at once: bank [bb, nb, c] -> k_out [bb, nb, c], vt_out [bb, c, ldv] (pad columns untouched)."""
+        if self._bank_blocks is None:
+            self._bank_blocks = [st["blocks"][0] for st in self._all_st()]
+        self._project_bank(self._bank_blocks[e], bank, k_out, vt_out)
 
     def run_block(self, layers, h, emb, ctx_kv, ctx_idx, mode, banks, bank_idx, nread, x1=None):
         """TimestepEmbedSequential.forward (openaimodel.py:79-108)."""

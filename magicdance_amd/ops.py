@@ -120,6 +120,12 @@ def select_row_f32(table, counter, row_offset, dst, width):
     return dst
 
 
+def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst):
+    _lib.check(_lib.load().md_gather_rows(_p(table), _p(seg), nseg, max_row_units, _p(counter), row_offset, _p(dst),
+                                          stream_ptr()), "md_gather_rows")
+    return dst
+
+
 def counter_add(counter, delta):
     _lib.check(_lib.load().md_counter_add(_p(counter), delta, stream_ptr()), "md_counter_add")
 

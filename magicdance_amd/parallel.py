@@ -4,12 +4,14 @@ dataset/tiktok_video_arnold_copy.py:128-131).
 
 Frames are independent given (pose_f, x_T, reference latent, text context, weights), so rank r owns a contiguous
 block of frames and runs them as one batch.  The only shared quantity is the appearance bank: with ``wonoise`` it
-depends on (reference latent, t, ctx) only, i.e. on the DDIM step but not on the frame.  The S banks (23 MB fp16 each
-at 512x512) are therefore computed once per sequence, round-robin over ranks (rank r runs the appearance net for the
-steps i with i % world == r), and exchanged with S RCCL broadcasts (point-to-point xGMI links: each broadcast is a
-direct root->peers fan-out of one 23 MB buffer).  After that the 50-step loop has no collective at all: every rank
-replays its captured step graph (pose ControlNet + UNet cond/uncond + CFG/DDIM update) reading bank row ``step``.
-Final latents are all-gathered (the decoded-frame gather of the north star, at the latent seam of this round's scope).
+depends on (reference latent, t, ctx) only, i.e. on the DDIM step but not on the frame.  The S banks are therefore
+computed once per sequence: rank r runs the appearance net for a contiguous block of S/world steps (batched over those
+timesteps) and applies the UNet's to_k / to_v to them -- the "reference-image KV" of the north star, 46 MB fp16 per
+step at 512x512 -- and the blocks are exchanged with RCCL broadcasts (point-to-point xGMI links: each broadcast is a
+direct root->peers fan-out of one contiguous table slab).  After that the 50-step loop has no collective at all:
+every rank replays its captured step graph (pose ControlNet + UNet cond/uncond + CFG/DDIM update) reading table row
+``step``.  Final latents are all-gathered (the decoded-frame gather of the north star, at the latent seam of this
+round's scope).
 """
 import torch
 
@@ -27,6 +29,26 @@ class FrameShardedSampler:
              "overlap_sampling": False}
         uc = {"c_concat": [pose], "c_crossattn": [rep(ctx)], "wonoise": True, "overlap_sampling": False}
         return c, uc
+
+    def row_block(self, S, rank):
+        """DDIM rows [r0, r1) whose reference-KV this rank computes (contiguous, as even as S % world allows)."""
+        q, r = divmod(S, self.world)
+        r0 = rank * q + min(rank, r)
+        return r0, r0 + q + (1 if rank < r else 0)
+
+    def _fill_table(self, st):
+        """Reference-KV table of the whole schedule: every rank runs the appearance net (batched over its block of
+        timesteps) for S/world rows and the blocks are exchanged with RCCL broadcasts -- each one a direct root->peers
+        fan-out over the point-to-point xGMI links of (row block x one bank entry's K or V^T), 32 pieces per rank."""
+        r0, r1 = self.row_block(st.S, self.rank)
+        st.compute_bank_rows(range(r0, r1))
+        if self.world > 1:
+            import torch.distributed as dist
+            for src in range(self.world):
+                s0, s1 = self.row_block(st.S, src)
+                if s1 > s0:
+                    for slab in st.table_slabs(s0, s1):
+                        dist.broadcast(slab, src=src, group=self.group)
 
     @torch.no_grad()
     def sample(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, gather=True):
@@ -50,9 +72,7 @@ class FrameShardedSampler:
         with torch.cuda.stream(st.stream):
             st.prepare(c, x_T, sampler, scale, table_mode=True)
             S = st.S
-            st.compute_bank_rows([i for i in range(S) if i % self.world == self.rank])
-            for i in range(S):  # reference-image bank ("ref-KV") broadcast over RCCL / xGMI
-                dist.broadcast(st.bank_table[i], src=i % self.world, group=self.group)
+            self._fill_table(st)
             for _ in range(S):
                 st.step()
             z = st.x.clone()
@@ -89,12 +109,7 @@ class FrameShardedSampler:
                 old_key = st.key
                 st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True)
                 if not have_table or st.key != old_key:   # (re)allocated buffers: the table must be filled for this geometry
-                    S = st.S
-                    st.compute_bank_rows([i for i in range(S) if i % self.world == self.rank])
-                    if self.world > 1:
-                        import torch.distributed as dist
-                        for i in range(S):
-                            dist.broadcast(st.bank_table[i], src=i % self.world, group=self.group)
+                    self._fill_table(st)
                     have_table = True
                 for _ in range(st.S):
                     st.step()
@@ -104,7 +119,14 @@ class FrameShardedSampler:
 
     @torch.no_grad()
     def profile_one_step(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0):
-        """Run ONE DDIM step as plain (un-captured) launches so md_prof_* can time every kernel."""
+        """Per-kernel-family time of ONE batch of frames: the reference-KV table pass (all S rows, once) plus ONE DDIM
+        step (x S), each (a) as plain un-captured launches timed per launch by md_prof_* and (b) -- igemm / attention --
+        replayed back-to-back from a captured graph between two HIP events on the launch stream.  Returns
+        {family: {ms, launches, flops, bytes, graph_ms, ...}} aggregated over the batch (table + S * step) with the two
+        parts under "table" / "step"."""
+        import ctypes as C
+        import os
+        from . import ops
         model = self.model
         c, _ = self._cond(pose, ctx, ref)
         sampler = DDIMSampler_ReferenceOnly(model)
@@ -112,22 +134,16 @@ class FrameShardedSampler:
         st = model._fused
         if st is None:
             st = model._fused = FusedStepRunner(model)
-        import ctypes as C
-        from . import ops
-        with torch.cuda.stream(st.stream):
-            st.prepare(c, x_T, sampler, scale, table_mode=False)
-            st._launch_sequence()          # sizes the arena / warms caches
-            st.stream.synchronize()
-            st.counter.zero_()
-            ops.prof_enable(True)          # (a) per-launch events, un-captured: includes the eager launch latency
+        table = os.environ.get("MD_BANK_MODE", "table") != "inline"
+
+        def timed(fn):
+            ops.prof_enable(True)
             ops.RECORD = []
-            st._launch_sequence()
+            fn()
             st.stream.synchronize()
             fam = ops.prof_collect()
             ops.prof_enable(False)
             rec, ops.RECORD = ops.RECORD, None
-            # (b) the same launches of one family replayed back-to-back from a captured graph on this stream, bracketed
-            #     by HIP events: average launch duration as the GPU sees it inside the step graph
             sp = ops.stream_ptr()
             for name in ("igemm", "attention"):
                 calls = [r for r in rec if r[0] == name]
@@ -135,8 +151,8 @@ class FrameShardedSampler:
                     continue
                 g = ops.Graph()
                 g.begin()
-                for _, fn, p, _, _ in calls:
-                    fn(C.byref(p), sp)
+                for _, fn_, p, _, _ in calls:
+                    fn_(C.byref(p), sp)
                 g.end()
                 g.launch()
                 st.stream.synchronize()
@@ -150,5 +166,26 @@ class FrameShardedSampler:
                 g.destroy()
                 fam[name]["graph_ms"] = e0.elapsed_time(e1) / reps
                 fam[name]["graph_launches"] = len(calls)
-                fam[name]["graph_flops"] = float(sum(r[3] for r in calls))
-        return fam
+            return fam
+
+        with torch.cuda.stream(st.stream):
+            st.prepare(c, x_T, sampler, scale, table_mode=table)
+            S = st.S
+            if table:
+                st.compute_bank_rows(range(S))   # warm: sizes the arenas
+            st._launch_sequence()
+            st.stream.synchronize()
+            st.counter.zero_()
+            parts = {"table": timed(lambda: st.compute_bank_rows(range(S))) if table else None,
+                     "step": timed(st._launch_sequence)}
+        out = {}
+        for name, stp in parts["step"].items():
+            tab = parts["table"][name] if parts["table"] is not None else None
+            agg = {}
+            for k in ("ms", "launches", "flops", "bytes", "graph_ms"):
+                if k in stp or (tab is not None and k in tab):
+                    agg[k] = S * stp.get(k, stp["ms"] if k == "graph_ms" else 0) + \
+                        (tab.get(k, tab["ms"] if k == "graph_ms" else 0) if tab is not None else 0)
+            agg["step"], agg["table"], agg["ddim_steps"] = stp, tab, S
+            out[name] = agg
+        return out

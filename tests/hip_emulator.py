@@ -143,6 +143,15 @@ def select_row_f32(table, counter, row_offset, dst, width):
     return dst
 
 
+def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst):
+    row = (int(counter[0]) if counter is not None else 0) + row_offset
+    tab, d = table.view(-1), dst.view(-1)
+    u = 16 // tab.element_size()
+    for off, ln, doff in seg.view(-1, 3).tolist()[:nseg]:
+        d[doff * u:(doff + ln) * u].copy_(tab[(off + row * ln) * u:(off + (row + 1) * ln) * u])
+    return dst
+
+
 def counter_add(counter, delta):
     counter += delta
 
@@ -206,7 +215,7 @@ def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
     for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "layernorm", "nchw_to_nhwc_f16",
-                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "counter_add",
+                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "counter_add",
                  "ddim_update", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)

@@ -317,3 +317,26 @@ def test_graph_and_profile(dev):
     ops.prof_enable(False)
     assert r["elementwise"]["launches"] == 1 and r["elementwise"]["ms"] > 0
     assert np.allclose(dst.cpu().numpy(), [6, 7, 8])
+
+
+def test_gather_rows(dev):
+    """md_gather_rows: multi-segment row pick of the reference-KV table (bit-exact copy, device-side row counter)."""
+    from magicdance_amd import ops
+    g = torch.Generator().manual_seed(0)
+    S, lens = 5, [8 * 3, 8 * 1000, 8 * 17]          # fp16 elements per row, per segment (16-byte multiples)
+    tabs = [torch.randn(S, ln, generator=g).half() for ln in lens]
+    table = torch.cat([t.reshape(-1) for t in tabs]).to(dev)
+    segs, toff, doff = [], 0, 0
+    for ln in lens:
+        segs.append((toff // 8, ln // 8, doff // 8))
+        toff += S * ln
+        doff += ln
+    seg = torch.tensor(segs, dtype=torch.int64, device=dev)
+    dst = torch.zeros(doff, dtype=F16, device=dev)
+    counter = torch.tensor([3], dtype=torch.int32, device=dev)
+    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), counter, 0, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), torch.cat([t[3] for t in tabs]))
+    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), None, 1, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), torch.cat([t[1] for t in tabs]))

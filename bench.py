@@ -3,8 +3,8 @@
 A "step" (driver contract) = one pass of the hot path over one batch of synthetic input = sampling ONE batch of
 `--frames-per-gpu` frames: the reference-KV table pass (appearance net for all 50 timesteps, batched over timesteps,
 plus the UNet's bank K/V projections) and the full 50-step DDIM loop (pose ControlNet + UNet cond/uncond + CFG/DDIM
-update per step), latents in -> latents out, inputs resident in HBM before the timed region; nothing is cached
-across batches (the table is recomputed for every batch).
+update per step) and the first-stage (VAE) decode of the frames, latents in -> decoded frames out, inputs resident in
+HBM before the timed region; nothing is cached across batches (the table is recomputed for every batch).
 N=1 default workload = BASELINE.json configs[1]: single 512x512 frame, 50-step DDIM, full Appearance+Pose ControlNet,
 fp16, random-init (seeded synthetic) SD-1.5-geometry weights.  N>1: one process per GPU (torch.distributed over RCCL),
 frames sharded across ranks (weak scaling: `--frames-per-gpu` each), the reference-image KV table computed in row
@@ -31,8 +31,7 @@ def build_model(device, size):
     import magicdance_amd as M
     from magicdance_amd import synthetic
     cfg = M.cldm.load_config(M.DEFAULT_CONFIG)["model"]
-    cfg["params"]["first_stage_config"] = "__is_first_stage__"   # VAE / CLIP are outside the timed path
-    cfg["params"]["cond_stage_config"] = "__is_unconditional__"
+    cfg["params"]["cond_stage_config"] = "__is_unconditional__"   # CLIP runs once per sequence, outside the timed path
     cfg["params"]["image_size"] = size
     with torch.device("meta"):
         model = M.instantiate_from_config(cfg)
@@ -43,16 +42,19 @@ def build_model(device, size):
     with torch.no_grad():
         for pre, mod in (("model.diffusion_model.", model.model.diffusion_model),
                          ("appearance_control_model.", model.appearance_control_model),
-                         ("pose_control_model.", model.pose_control_model)):
+                         ("pose_control_model.", model.pose_control_model),
+                         ("first_stage_model.", model.first_stage_model)):
             sd = synthetic.synth_state_dict(mod, pre, seed=0, device=device)
             mod.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=True)
     return model.eval()
 
 
-def cpu_baseline(model, inp, size, max_seconds=40.0):
-    """The CPU oracle (oracle/restatement.py, torch fp32) on this box's host cores, bounded sample: ONE DDIM step
-    (cond + uncond apply_model) of the same single-frame workload; frames/s extrapolated to the full 50 steps."""
+def cpu_baseline(model, inp, size, z_hip=None, img_hip=None):
+    """The CPU oracle (oracle/restatement.py + oracle/vae_restatement.py, torch fp32) on this box's host cores, bounded
+    sample: ONE DDIM step (cond + uncond apply_model) of the same single-frame workload plus the first-stage decode of
+    one frame; frames/s = 1 / (50 x step + decode)."""
     from oracle import restatement as R
+    from oracle import vae_restatement as V
     sd = {}
     for pre, mod in (("model.diffusion_model.", model.model.diffusion_model),
                      ("appearance_control_model.", model.appearance_control_model),
@@ -75,10 +77,20 @@ def cpu_baseline(model, inp, size, max_seconds=40.0):
         h_c = model.apply_model(inp["x_T"], t.to(dev), cd, inp["ref"]).cpu()
         h_u = model.apply_model(inp["x_T"], t.to(dev), cd, None, uc=True).cpu()
         rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
-    return {"value": 1.0 / (50.0 * dt), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 50 DDIM steps (cond+uncond apply_model, 1 frame {8 * size}x{8 * size}) = {dt:.1f}s, x50 extrapolated",
-            "parity_full_size": {"eps_cond_rel_max_abs": rel(h_c, e_c), "eps_uncond_rel_max_abs": rel(h_u, e_u),
-                                 "note": "HIP fp16 path vs fp32 CPU oracle, t=981, same synthetic weights/inputs"}}
+        parity = {"eps_cond_rel_max_abs": rel(h_c, e_c), "eps_uncond_rel_max_abs": rel(h_u, e_u),
+                  "note": "HIP fp16 path vs fp32 CPU oracle, t=981, same synthetic weights/inputs"}
+        dt_vae = 0.0
+        if z_hip is not None:
+            pre = "first_stage_model."
+            vsd = {pre + k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
+            t0 = time.time()
+            img = V.vae_decode(vsd, pre, z_hip[:1].cpu() / model.scale_factor)
+            dt_vae = time.time() - t0
+            parity["decode_rel_max_abs"] = rel(img_hip[:1].cpu(), img)
+    return {"value": 1.0 / (50.0 * dt + dt_vae), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 50 DDIM steps (cond+uncond apply_model, 1 frame {8 * size}x{8 * size}) = {dt:.1f}s, x50 extrapolated"
+                      + (f", + first-stage decode of the frame = {dt_vae:.1f}s" if z_hip is not None else ""),
+            "parity_full_size": parity}
 
 
 def main():
@@ -94,6 +106,7 @@ def main():
                          "(bank table computed once per sequence), sampled in batches of --frames-per-gpu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="stop at the latents (skip the first-stage decode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,8 +135,9 @@ def main():
 
     def one_batch():
         if args.sequence:
-            return runner.sample_sequence(seq_pose, ctx, ref, inp["x_T"], frames_per_batch=fpg, ddim_steps=args.ddim_steps, scale=7.0)
-        return runner.sample(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
+            return runner.sample_sequence(seq_pose, ctx, ref, inp["x_T"], frames_per_batch=fpg, ddim_steps=args.ddim_steps,
+                                          scale=7.0, decode=not args.no_decode)
+        return runner.sample(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
 
     for _ in range(args.warmup):
         one_batch()
@@ -150,14 +164,15 @@ def main():
            "config": {"workload": (f"sequence of {args.sequence} frames/GPU sharing one reference (bank table once per sequence), "
                                    f"batches of {fpg}, " if args.sequence else f"configs[1]: {fpg} frame(s)/GPU ") +
                                   f"{8 * args.size}x{8 * args.size}, {args.ddim_steps}-step DDIM, "
-                                  "appearance + pose ControlNet + UNet cond/uncond, CFG 7, latents in -> latents out",
+                                  "appearance + pose ControlNet + UNet cond/uncond, CFG 7, latents in -> " +
+                                  ("latents out" if args.no_decode else "first-stage-decoded frames out"),
                       "frames_per_gpu": fpg, "ddim_steps": args.ddim_steps, "weights": "seeded synthetic, SD-1.5 geometry",
                       "parallelism": f"frame-shard x{world}"}}
     if rank == 0 and not args.no_roofline:
         # every kernel family over ONE batch of frames = the reference-KV table pass (once) + S x one DDIM step: per-launch
         # HIP events on un-captured launches (ms_eager_events, includes eager launch latency) and, for igemm / attention,
         # the same launches replayed from a captured graph between two HIP events on the launch stream (graph_ms)
-        fam = runner.profile_one_step(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0)
+        fam = runner.profile_one_step(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
         ig = fam["igemm"]
         ig_ms = ig.get("graph_ms", ig["ms"])
         ach = ig["flops"] / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
@@ -176,21 +191,25 @@ def main():
             ms = d.get("graph_ms", d["ms"])
             return {"ms": ms, "launches": d["launches"], "tflops": d["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one batch: reference-KV table pass + "
-                           f"{ig['ddim_steps']} DDIM steps)", "achieved": ach,
+                           f"{ig['ddim_steps']} DDIM steps" + ("" if args.no_decode else " + first-stage decode") + ")", "achieved": ach,
                            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
                            "traffic_unit": "bytes/launch (PMC, profiles/round1_pmc_summary.json)",
                            "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
                            "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,
-                           "ms_eager_events": ig["ms"], "table_pass": part(ig["table"]), "ddim_step": part(ig["step"])}
+                           "ms_eager_events": ig["ms"], "table_pass": part(ig["table"]), "ddim_step": part(ig["step"]),
+                           "first_stage_decode": part(ig["decode"])}
         out["families_ms_per_batch"] = {k: {"ms": v["ms"], "graph_ms": v.get("graph_ms"), "launches": v["launches"],
                                             "step_ms": v["step"].get("graph_ms", v["step"]["ms"]),
                                             "table_ms": None if v["table"] is None else v["table"].get("graph_ms", v["table"]["ms"]),
+                                            "decode_ms": None if v["decode"] is None else v["decode"].get("graph_ms", v["decode"]["ms"]),
                                             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
                                             "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
                                         for k, v in fam.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, inp, args.size)
+        z_one = runner.sample(pose[:1], ctx, ref, x_T[:1], ddim_steps=args.ddim_steps, scale=7.0) if not args.no_decode else None
+        out["cpu_baseline"] = cpu_baseline(model, inp, args.size, z_one,
+                                           None if z_one is None else model.decode_first_stage(z_one))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -75,6 +75,9 @@ typedef struct {
   int64_t ws_bytes;
   int32_t force_cfg;       /* -1 auto; otherwise tile config index (tests / tuning) */
   int32_t force_splitk;    /* 0 auto; otherwise number of K splits */
+  int32_t asym_pad;        /* 1: no padding on the top/left side, taps of output (oy, ox) start at source (stride*oy,
+                            * stride*ox) and run off the bottom/right edge into zeros: the VAE encoder's Downsample,
+                            * F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (ldm/modules/diffusionmodules/model.py:80-84) */
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
@@ -139,6 +142,11 @@ int md_nhwc_to_nchw_f32(const void* x, int32_t x_is_f32, float* out, int32_t bat
 /* out = a + b (fp16, n % 8 == 0); b_batch may broadcast: b index = i % b_period.  (pose residual adds,
  * cldm/cldm.py:93-95,102-104; guided-hint add :744-747) */
 int md_add_f16(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream);
+/* row softmax of fp32 scores to fp16 probabilities: p[r][j] = softmax_j(scale * s[r][j]), rows x cols, leading
+ * dimensions in elements (cols % 4 == 0).  Second stage of the VAE mid-block attention (single head, d = 512:
+ * AttnBlock.forward, ldm/modules/diffusionmodules/model.py:179-203), whose QK^T and PV contractions run on md_igemm. */
+int md_softmax_rows(const float* s, int64_t ld_s, void* p, int64_t ld_p, int32_t rows, int32_t cols, float scale,
+                    void* stream);
 /* sinusoidal timestep embedding (ldm/modules/diffusionmodules/util.py:189-209): out fp32 [nt][dim] */
 int md_timestep_embedding(const float* t, float* out, int32_t nt, int32_t dim, float max_period, void* stream);
 /* y[r][n] = bias[n] + sum_k act(x[r][k]) * w[n][k]; x fp32 [rows][k], w fp16 [n][k], y fp32; rows <= 64.

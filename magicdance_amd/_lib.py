@@ -23,7 +23,7 @@ class IgemmParams(C.Structure):
         ("bias_batch_stride", C.c_int64), ("res", C.c_void_p), ("ld_res", C.c_int32), ("act", C.c_int32),
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32), ("out_t", C.c_void_p),
         ("n_tr_begin", C.c_int32), ("ld_t", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-        ("force_cfg", C.c_int32), ("force_splitk", C.c_int32),
+        ("force_cfg", C.c_int32), ("force_splitk", C.c_int32), ("asym_pad", C.c_int32),
     ]
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "md_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "md_gemv_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "md_select_row_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    "md_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),
     "md_gather_rows": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp]),
     "md_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "md_ddim_update": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

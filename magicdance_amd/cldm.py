@@ -186,7 +186,7 @@ class ControlLDMReferenceOnlyPose(nn.Module):
         self._fused = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    # ------------------------------------------------------------------ VAE / CLIP glue (delegation only)
+    # ------------------------------------------------------------------ VAE / CLIP glue (the VAE is magicdance_amd.autoencoder)
     def get_learned_conditioning(self, c):
         if self.cond_stage_model is None:
             raise RuntimeError("no cond_stage_model: pass the [B,77,768] context tensor directly")

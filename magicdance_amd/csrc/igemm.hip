@@ -489,6 +489,7 @@ int validate(const md_igemm_params* p) {
   if (p->ksize != 1 && p->ksize != 3) return MD_ERR_UNSUPPORTED;
   if (p->stride != 1 && p->stride != 2) return MD_ERR_UNSUPPORTED;
   if (p->ups && (p->ksize != 3 || p->stride != 1)) return MD_ERR_UNSUPPORTED;
+  if (p->asym_pad && (p->ksize != 3 || p->ups)) return MD_ERR_UNSUPPORTED;
   if (p->c0 <= 0 || (p->c0 & 7) || p->c1 < 0 || (p->c1 & 7)) return MD_ERR_BAD_ARG;
   if ((p->c1 > 0) != (p->a1 != nullptr)) return MD_ERR_BAD_ARG;
   if (p->n <= 0 || (p->n & 3) || (p->ld_out & 3)) return MD_ERR_BAD_ARG;
@@ -596,7 +597,7 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.ksize = p->ksize;
   g.stride = p->stride;
   g.ups = p->ups;
-  g.pad = p->ksize / 2;
+  g.pad = p->asym_pad ? 0 : p->ksize / 2;
   g.w = (const half_t*)p->w;
   const long long M = (long long)p->batch * g.tokens;
   if (M >= (1LL << 24)) return MD_ERR_BAD_ARG;  // fast_div domain

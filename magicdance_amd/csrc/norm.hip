@@ -291,6 +291,72 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   return MD_OK;
 }
 
+// Row softmax, fp32 scores -> fp16 probabilities: one 256-thread block per row, the row held in registers
+// (cols <= 16384), max and sum reduced wave-wise then across the four waves through LDS.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long long ld_s,
+                                                           half_t* __restrict__ p, long long ld_p, int cols,
+                                                           float scale_log2e) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sr = s + (long long)blockIdx.x * ld_s;
+  half_t* pr = p + (long long)blockIdx.x * ld_p;
+  const int c4 = cols >> 2;
+  f4 v[16];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = tid + 256 * j;
+    if (i < c4) {
+      v[j] = *reinterpret_cast<const f4*>(sr + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, v[j][e]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = tid + 256 * j;
+    if (i < c4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[j][e] = exp2f(v[j][e] * scale_log2e - mx);
+        sum += v[j][e];
+      }
+    }
+  }
+  sum = md::wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = tid + 256 * j;
+    if (i < c4) {
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(v[j][e] * inv);
+      *reinterpret_cast<h4*>(pr + i * 4) = o;
+    }
+  }
+}
+
+extern "C" int md_softmax_rows(const float* s, int64_t ld_s, void* p, int64_t ld_p, int32_t rows, int32_t cols, float scale,
+                               void* stream) {
+  if (!s || !p || rows <= 0 || cols <= 0 || ld_s < cols || ld_p < cols) return MD_ERR_BAD_ARG;
+  if ((cols & 3) || (ld_s & 3) || (ld_p & 3) || cols > 16384 || scale <= 0.f) return MD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_NORM, st, 0.0, (double)rows * cols * 6.0);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, (long long)ld_s, (half_t*)p,
+                     (long long)ld_p, cols, scale * 1.44269504088896340736f);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 extern "C" int md_layernorm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
                             float eps, void* stream) {
   if (!x || !gamma || !beta || !out || rows <= 0) return MD_ERR_BAD_ARG;

@@ -23,7 +23,7 @@ RECORD = None
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0):
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False):
     """See md_igemm.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
@@ -37,7 +37,7 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.out, p.ld_out, p.out_f32 = _p(out), (ld_out if ld_out is not None else n), int(out_f32)
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
     p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
-    p.force_cfg, p.force_splitk = force_cfg, force_splitk
+    p.force_cfg, p.force_splitk, p.asym_pad = force_cfg, force_splitk, int(asym_pad)
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
@@ -83,6 +83,11 @@ def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=
 def layernorm(x, gamma, beta, out, rows, c, eps=1e-5):
     _lib.check(_lib.load().md_layernorm(_p(x), _p(gamma), _p(beta), _p(out), rows, c, eps, stream_ptr()), "md_layernorm")
     return out
+
+
+def softmax_rows(s, ld_s, p, ld_p, rows, cols, scale):
+    _lib.check(_lib.load().md_softmax_rows(_p(s), ld_s, _p(p), ld_p, rows, cols, scale, stream_ptr()), "md_softmax_rows")
+    return p
 
 
 def nchw_to_nhwc_f16(x, out, batch, c, hw, cpad):

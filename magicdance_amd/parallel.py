@@ -51,16 +51,17 @@ class FrameShardedSampler:
                         dist.broadcast(slab, src=src, group=self.group)
 
     @torch.no_grad()
-    def sample(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, gather=True):
+    def sample(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, gather=True, decode=False):
         """pose [Bl,3,8h,8w] = this rank's frames; ctx [1,77,768]; ref [1,4,h,w]; x_T [Bl,4,h,w].
-        Returns the latents of ALL frames ([world*Bl,4,h,w], rank order) when ``gather`` else this rank's."""
+        Returns the latents -- or, with ``decode``, the first-stage-decoded frames [.,3,8h,8w] -- of ALL frames
+        (rank order) when ``gather`` else this rank's."""
         model = self.model
         c, uc = self._cond(pose, ctx, ref)
         if self.world == 1:
             z, _ = model.sample_log(cond=c, batch_size=pose.shape[0], ddim=True, ddim_steps=ddim_steps, eta=0.0,
                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc, inpaint=None,
                                     x_T=x_T)
-            return z
+            return model.decode_first_stage(z) if decode else z
         import torch.distributed as dist
         sampler = DDIMSampler_ReferenceOnly(model)
         sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
@@ -76,7 +77,9 @@ class FrameShardedSampler:
             for _ in range(S):
                 st.step()
             z = st.x.clone()
-            if gather:
+            if decode:
+                z = model.decode_first_stage(z)
+            if gather:   # the all-gather of decoded frames of the north star (latents when the caller decodes itself)
                 outs = [torch.empty_like(z) for _ in range(self.world)]
                 dist.all_gather(outs, z, group=self.group)
                 z = torch.cat(outs, 0)
@@ -84,7 +87,7 @@ class FrameShardedSampler:
         return z
 
     @torch.no_grad()
-    def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0):
+    def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0, decode=False):
         """A whole pose sequence sharing one reference image (the entry points' use case, test_any_image_pose.py:201-262:
         same ref latent, same text, same x_T for every frame).  With ``wonoise`` the appearance bank depends on the DDIM
         step only, so the S banks are computed ONCE per sequence (round-robin over ranks + RCCL broadcast when world > 1)
@@ -113,17 +116,17 @@ class FrameShardedSampler:
                     have_table = True
                 for _ in range(st.S):
                     st.step()
-                outs.append(st.x.clone())
+                outs.append(model.decode_first_stage(st.x) if decode else st.x.clone())
         caller.wait_stream(st.stream)
         return torch.cat(outs, 0)
 
     @torch.no_grad()
-    def profile_one_step(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0):
-        """Per-kernel-family time of ONE batch of frames: the reference-KV table pass (all S rows, once) plus ONE DDIM
-        step (x S), each (a) as plain un-captured launches timed per launch by md_prof_* and (b) -- igemm / attention --
+    def profile_one_step(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, decode=False):
+        """Per-kernel-family time of ONE batch of frames: the reference-KV table pass (all S rows, once), ONE DDIM
+        step (x S) and (``decode``) the first-stage decode of the batch, each (a) as plain un-captured launches timed per launch by md_prof_* and (b) -- igemm / attention --
         replayed back-to-back from a captured graph between two HIP events on the launch stream.  Returns
-        {family: {ms, launches, flops, bytes, graph_ms, ...}} aggregated over the batch (table + S * step) with the two
-        parts under "table" / "step"."""
+        {family: {ms, launches, flops, bytes, graph_ms, ...}} aggregated over the batch (table + S * step + decode) with
+        the parts under "table" / "step" / "decode"."""
         import ctypes as C
         import os
         from . import ops
@@ -178,14 +181,20 @@ class FrameShardedSampler:
             st.counter.zero_()
             parts = {"table": timed(lambda: st.compute_bank_rows(range(S))) if table else None,
                      "step": timed(st._launch_sequence)}
+            if decode:
+                z = st.x.clone()
+                model.decode_first_stage(z)          # warm: sizes the arena
+                parts["decode"] = timed(lambda: model.decode_first_stage(z))
         out = {}
         for name, stp in parts["step"].items():
-            tab = parts["table"][name] if parts["table"] is not None else None
+            once = [parts[k][name] for k in ("table", "decode") if parts.get(k) is not None]
             agg = {}
             for k in ("ms", "launches", "flops", "bytes", "graph_ms"):
-                if k in stp or (tab is not None and k in tab):
+                if k in stp or any(k in o for o in once):
                     agg[k] = S * stp.get(k, stp["ms"] if k == "graph_ms" else 0) + \
-                        (tab.get(k, tab["ms"] if k == "graph_ms" else 0) if tab is not None else 0)
-            agg["step"], agg["table"], agg["ddim_steps"] = stp, tab, S
+                        sum(o.get(k, o["ms"] if k == "graph_ms" else 0) for o in once)
+            agg["step"], agg["ddim_steps"] = stp, S
+            agg["table"] = parts["table"][name] if parts.get("table") is not None else None
+            agg["decode"] = parts["decode"][name] if parts.get("decode") is not None else None
             out[name] = agg
         return out

@@ -8,7 +8,7 @@ import zlib
 
 import torch
 
-_NORM_TAGS = ("in_layers.0.", "out_layers.0.", ".norm.", ".norm1.", ".norm2.", ".norm3.", "out.0.")
+_NORM_TAGS = ("in_layers.0.", "out_layers.0.", ".norm.", ".norm1.", ".norm2.", ".norm3.", "out.0.", ".norm_out.")
 # layers the reference zero-initialises (openaimodel.py:249-251,749; attention.py:357; cldm.py:614,733):
 _ZERO_INIT_TAGS = ("out_layers.3.", ".proj_out.", "zero_convs.", "middle_block_out.", "out.2.",
                    "input_hint_block.14.")
@@ -55,3 +55,12 @@ def synth_inputs(latent_hw=(64, 64), frames=1, seed=0, ctx_tokens=77, ctx_dim=76
     pose = torch.rand(frames, 3, 8 * h, 8 * w, generator=g(4))
     x_T = torch.randn(1, 4, h, w, generator=g(5))
     return dict(ref=ref.to(device), ctx=ctx.to(device), pose=pose.to(device), x_T=x_T.to(device))
+
+
+def synth_vae_inputs(side, batch=1, seed=0, device="cpu"):
+    """First-stage inputs: a latent z [B,4,side,side] (unit normal = latent / scale_factor scale) for decode and an
+    image [B,3,8*side,8*side] in [-1,1] for encode."""
+    g = lambda s: torch.Generator(device="cpu").manual_seed(seed * 1000 + s)
+    z = torch.randn(batch, 4, side, side, generator=g(11))
+    img = torch.rand(batch, 3, 8 * side, 8 * side, generator=g(12)) * 2 - 1
+    return z.to(device), img.to(device)

@@ -87,6 +87,42 @@ def run_case(name):
     print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
 
 
+VAE_CASES = {
+    # name: (ddconfig overrides, latent side, batch).  Images / moments of the small cases are stored in full, the
+    # SD-1.5-geometry ones as a stride-4 subsample + summary statistics.
+    "vae_small": (dict(ch=32), 8, 2),
+    "vae_full16": (dict(), 16, 1),
+    "vae_full64": (dict(), 64, 1),
+}
+VAE_PREFIX = "first_stage_model."
+
+
+def run_vae_case(name):
+    from oracle.vae_restatement import SD15_DDCONFIG
+    over, side, batch = VAE_CASES[name]
+    t0 = time.time()
+    dd = dict(SD15_DDCONFIG, **over)
+    torch.manual_seed(0)
+    vae = ref_shim.build_reference_vae(dd)
+    sd = synthetic.synth_state_dict(vae, VAE_PREFIX, seed=0)
+    missing = vae.load_state_dict({k[len(VAE_PREFIX):]: v for k, v in sd.items()}, strict=True)
+    z, img = synthetic.synth_vae_inputs(side, batch, seed=0)
+    with torch.no_grad():
+        dec = vae.decode(z)
+        post = vae.encode(img)
+    mom = post.parameters
+    out = dict(ch=dd["ch"], side=side, batch=batch, seed=0, z_sum=summarize(z), img_sum=summarize(img),
+               dec_sum=summarize(dec), mom_sum=summarize(mom), mean_sum=summarize(post.mean), std_sum=summarize(post.std))
+    out["state_keys"] = np.array("\n".join(f"{k}:{tuple(v.shape)}" for k, v in vae.state_dict().items()))
+    if dd["ch"] == 128 and side > 16:
+        out["dec_sub"], out["mom"] = dec[:, :, ::4, ::4].contiguous().numpy(), mom.numpy()
+    else:
+        out["dec"], out["mom"] = dec.numpy(), mom.numpy()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s", missing)
+
+
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES)):
-        run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(VAE_CASES)):
+        run_vae_case(n) if n in VAE_CASES else run_case(n)

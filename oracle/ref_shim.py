@@ -91,7 +91,8 @@ def load_reference():
     import model_lib.ControlNet.ldm.modules.diffusionmodules.util as util
 
     ddim.DDIMSampler_ReferenceOnly.register_buffer = lambda self, n, a: setattr(self, n, a)
-    _LOADED.update(cldm=cldm, ddim=ddim, attention=att, openaimodel=oam, util=util,
+    from model_lib.ControlNet.ldm.models import autoencoder
+    _LOADED.update(cldm=cldm, ddim=ddim, attention=att, openaimodel=oam, util=util, autoencoder=autoencoder, vae_modules=vae,
                    instantiate_from_config=instantiate_from_config)
     return types.SimpleNamespace(**_LOADED)
 
@@ -122,3 +123,11 @@ def build_reference_model(overrides=None, image_size=None, with_vae=False):
     if image_size is not None:
         model.image_size = image_size
     return model
+
+
+def build_reference_vae(ddconfig):
+    """The unmodified reference AutoencoderKL (ldm/models/autoencoder.py) with the vanilla AttnBlock (xformers absent,
+    ldm/modules/diffusionmodules/model.py:280-293)."""
+    ref = load_reference()
+    return ref.autoencoder.AutoencoderKL(ddconfig=dict(ddconfig), lossconfig={"target": "torch.nn.Identity"},
+                                         embed_dim=ddconfig["z_channels"]).eval()

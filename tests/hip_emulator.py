@@ -19,7 +19,7 @@ def _mem(t, size, stride):
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0):
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False):
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -29,7 +29,10 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
         x = F.interpolate(x, scale_factor=2, mode="nearest")
     kk = ksize * ksize * cin
     wt = _mem(w, (n, ksize, ksize, cin), (kk, ksize * cin, cin, 1)).float().permute(0, 3, 1, 2)
-    y = F.conv2d(x, wt, stride=stride, padding=ksize // 2)
+    if asym_pad:
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, stride=stride, padding=0)
+    else:
+        y = F.conv2d(x, wt, stride=stride, padding=ksize // 2)
     assert y.shape[2] == hout and y.shape[3] == wout, (y.shape, hout, wout)
     tokens = hout * wout
     y = y.permute(0, 2, 3, 1).reshape(batch, tokens, n)
@@ -137,6 +140,11 @@ def gemv_f32(x, w, bias, y, rows, k, n, act_in=False):
     return y
 
 
+def softmax_rows(s, ld_s, p, ld_p, rows, cols, scale):
+    _mem(p, (rows, cols), (ld_p, 1)).copy_((_mem(s, (rows, cols), (ld_s, 1)).float() * scale).softmax(-1))
+    return p
+
+
 def select_row_f32(table, counter, row_offset, dst, width):
     row = (int(counter[0]) if counter is not None else 0) + row_offset
     _mem(dst, (width,), (1,)).copy_(_mem(table, (row + 1, width), (width, 1))[row])
@@ -215,7 +223,7 @@ def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
     for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "layernorm", "nchw_to_nhwc_f16",
-                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "counter_add",
+                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)

@@ -1,0 +1,80 @@
+"""GPU tier: the first-stage model (VAE decode / encode) on the HIP kernels through the C ABI, against the goldens
+produced by the unmodified reference AutoencoderKL (fp32 CPU).  Tolerances: fp16 activations / fp32 accumulate through
+~60 layers; relative to the output's max-abs, stated at the assert."""
+import numpy as np
+import pytest
+import torch
+
+from magicdance_amd import synthetic
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+F16, F32 = torch.float16, torch.float32
+TOL_DEC, TOL_MOM = 8e-3, 8e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    r = float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+    with open("gpurun_out/parity_vae.log", "a") as f:
+        f.write(f"{what}: rel max-abs {r:.3e} (max|ref| {np.abs(b).max():.3f})\n")
+    return r
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_full16", "vae_full64"])
+def test_vae_matches_reference_golden(dev, name):
+    g = H.load_golden(name)
+    vae = H.build_hip_vae(int(g["ch"]), seed=int(g["seed"]), device=dev)
+    z, img = synthetic.synth_vae_inputs(int(g["side"]), int(g["batch"]), seed=int(g["seed"]), device=dev)
+    dec = vae.decode(z)
+    assert dec.dtype == F32 and tuple(dec.shape) == (z.shape[0], 3, 8 * z.shape[2], 8 * z.shape[3])
+    if "dec" in g:
+        assert _rel(dec.cpu().numpy(), g["dec"], f"{name} decode") <= TOL_DEC
+    else:
+        assert _rel(dec[:, :, ::4, ::4].cpu().numpy(), g["dec_sub"], f"{name} decode (stride-4 subsample)") <= TOL_DEC
+        s = H.summarize(dec.cpu())
+        assert abs(s[3] - g["dec_sum"][3]) <= 2e-3 * g["dec_sum"][3]
+    mom = vae.encode(img).parameters
+    assert _rel(mom.cpu().numpy(), g["mom"], f"{name} encode moments") <= TOL_MOM
+    # a frame decoded alone equals the same frame decoded in a batch (no cross-sample term anywhere)
+    if z.shape[0] > 1:
+        assert torch.equal(vae.decode(z[1:2]), dec[1:2])
+
+
+def test_softmax_rows(dev):
+    from magicdance_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for rows, cols, ld in ((7, 64, 64), (33, 4096, 4096), (5, 9216, 9216), (3, 100, 128)):
+        s = (torch.randn(rows, ld, generator=g) * 30).to(dev)
+        p = torch.zeros(rows, ld, dtype=F16, device=dev)
+        ops.softmax_rows(s, ld, p, ld, rows, cols, 0.125)
+        ref = (s[:, :cols].double() * 0.125).softmax(-1)
+        assert float((p[:, :cols].double() - ref).abs().max()) <= 6e-4
+        assert float(p[:, cols:].abs().max()) == 0.0 if ld > cols else True
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 32, 32, 128, 128), (1, 10, 14, 8, 32)])
+def test_igemm_asym_pad_stride2(dev, shape):
+    """Downsample of the VAE encoder: F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (model.py:80-84)."""
+    from magicdance_amd import ops
+    from magicdance_amd.engine import pack_conv
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.half().float(), (0, 1, 0, 1)), wt.half().float(), bias, stride=2)
+    xn = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    out = torch.empty(b, (h // 2) * (w // 2), cout, dtype=F16, device=dev)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
+    for cfg in (-1, 0, 4):
+        ops.igemm(xn, pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h // 2, wout=w // 2, c0=cin, ksize=3, stride=2,
+                  bias=bias.to(dev), out=out, ws=ws, asym_pad=True, force_cfg=cfg)
+        got = out.float().cpu().reshape(b, h // 2, w // 2, cout).permute(0, 3, 1, 2)
+        assert float((got - ref).abs().max()) <= 2e-2, cfg

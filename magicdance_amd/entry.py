@@ -116,7 +116,9 @@ def run(args, need_dataset=False):
         model.load_state_dict(M.load_state_dict(args.image_pretrain_dir, location="cpu"), strict=True)
     elif args.synthetic_weights:
         for pre, mod in (("model.diffusion_model.", model.model.diffusion_model), ("appearance_control_model.", model.appearance_control_model),
-                         ("pose_control_model.", model.pose_control_model)):
+                         ("pose_control_model.", model.pose_control_model), ("first_stage_model.", model.first_stage_model)):
+            if mod is None or isinstance(mod, _Unavailable):
+                continue
             sd = synthetic.synth_state_dict(mod, pre, seed=0)
             mod.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=True)
     else:

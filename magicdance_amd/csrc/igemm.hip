@@ -32,7 +32,7 @@ struct IgemmArgs {
   const half_t* w;
   int M, N, K;
   int nk, splitk, tiles_per_split;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group_m;
   unsigned div_tok_mul, div_tok_sh, div_w_mul, div_w_sh;  // exact n / tokens and n / wout for n < 2^24 (fast_div)
   // epilogue
   const float* bias;
@@ -47,6 +47,7 @@ struct IgemmArgs {
   int n_tr_begin;
   int ld_t;
   float* ws;
+  int dbg;  // MD_IGEMM_DEBUG bit mask (component timing only, results are garbage): 1 no MFMA, 2 no LDS reads + MFMA, 4 no k-loop loads
 };
 
 // n / d for n < 2^24: q = (n * mul) >> sh with mul = floor(2^sh / d) + 1, sh = 24 + ceil(log2 d) (host side below)
@@ -127,7 +128,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = logical % g.tiles_m, tile_n = logical / g.tiles_m;
+  // grouped raster inside the XCD's contiguous range: group_m m-tiles x all n-tiles are consecutive, so the ~64 workgroups
+  // resident on one XCD at a time share group_m A tiles and tiles_n W panels (both re-read from that XCD's L2)
+  const int per_group = g.group_m * g.tiles_n;
+  const int grp = logical / per_group, in_grp = logical - grp * per_group;
+  const int first_m = grp * g.group_m;
+  const int gsz = min(g.tiles_m - first_m, g.group_m);
+  const int tile_n = in_grp / gsz, tile_m = first_m + (in_grp - tile_n * gsz);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kz = blockIdx.z;
   const int kt_begin = kz * g.tiles_per_split;
@@ -198,16 +205,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 
   // BUF loader: the launcher guarantees cin % 64 == 0 and c0 % 64 == 0, so a 64-channel k-tile lies in ONE tap of ONE
   // source: tap / source / channel base are wave-uniform scalars advanced per tile (no waterfall on the descriptor).
-  int kt_u = kt_begin * 64, tap_u = 0, cc_u = kt_begin * 64;
+  // k-tile ORDER of the 3x3 convs: channel-block outer, tap inner (k-tile t -> channels 64*(t/9).., tap t%9).  The nine
+  // taps of one 64-channel block re-read the same (BM + halo) pixels x 128 B, so the A operand is served from L1/L2 instead
+  // of being re-streamed from the Infinity Cache nine times per pass (the tap-outer order had a reuse distance of a whole
+  // Cin sweep, ~BM*Cin*2 B per workgroup, x 64 resident workgroups per XCD >> the 4 MB L2).  W's k offset follows.
+  int kt_i = kt_begin, tap_u = 0, cc_u = kt_begin * 64;
   if (g.ksize == 3) {
-    tap_u = kt_u / g.cin;
-    cc_u = kt_u - tap_u * g.cin;
+    const int cb = kt_begin / 9;
+    tap_u = kt_begin - cb * 9;
+    cc_u = cb * 64;
   }
   auto fetch_tile = [&](int stage, bool tile_valid = true) {  // loads the tile at (k_cur, tap, cc), then advances
     char* As = smem + stage * STAGE_BYTES;
     char* Ws = As + BM * 128;
     if constexpr (BUF) {
-      const bool kvalid = tile_valid && kt_u < g.K;  // uniform (K % 64 == 0 here)
+      const bool kvalid = tile_valid && kt_i < g.nk;  // uniform (K % 64 == 0 here)
       const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
       const bool second = cc_u >= g.c0;
       const unsigned cs = second ? g.c1 : g.c0;
@@ -239,16 +251,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
                                                    16, voff[j], soff, 0, 0);
       }
-      const unsigned ksoff = (unsigned)kt_u * 2u;
+      const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
 #pragma unroll
       for (int j = 0; j < WJ; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
                                                  16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
-      kt_u += 64;
-      cc_u += 64;
-      if (g.ksize == 3 && cc_u >= g.cin) {
-        cc_u -= g.cin;
-        ++tap_u;
+      ++kt_i;
+      if (g.ksize == 3) {
+        if (++tap_u == 9) {
+          tap_u = 0;
+          cc_u += 64;
+        }
+      } else {
+        cc_u += 64;
       }
       return;
     }
@@ -311,6 +326,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   auto compute_tile = [&](int stage) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Ws = As + BM * 128;
+    if (g.dbg & 2) return;
+    if (g.dbg & 1) {  // LDS operand reads only
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 4 + lg;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int row = wm * WTM + i * 16 + lr;
+          const h8 v = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ (row & 7)) << 4));
+          asm volatile("" ::"v"(v));
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int row = wn * WTN + i * 16 + lr;
+          const h8 v = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ (row & 7)) << 4));
+          asm volatile("" ::"v"(v));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       h8 af[MF], wf[NF];
@@ -365,7 +400,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt has landed for every wave; every wave is done with stage^1
-        if (more) fetch_tile(stage ^ 1);
+        if (more && !(g.dbg & 4)) fetch_tile(stage ^ 1);
       } else {
         if (more) fetch_tile(stage ^ 1);
       }
@@ -619,6 +654,11 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.n_tr_begin = p->n_tr_begin;
   g.ld_t = p->ld_t;
   g.ws = (float*)p->ws;
+  static const int dbg = [] {
+    const char* e = getenv("MD_IGEMM_DEBUG");
+    return e ? atoi(e) : 0;
+  }();
+  g.dbg = dbg;
   int cfg, split;
   choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split);
   if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
@@ -628,6 +668,16 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
   g.tiles_n = (g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn;
+  {  // ~64 workgroups are resident per XCD: make them a (group_m x tiles_n) block of the tile grid
+    static const int gm_env = [] {
+      const char* e = getenv("MD_IGEMM_GROUP_M");
+      return e ? atoi(e) : 0;
+    }();
+    int gm = gm_env > 0 ? gm_env : (64 + g.tiles_n - 1) / g.tiles_n;
+    if (gm < 1) gm = 1;
+    if (gm > g.tiles_m) gm = g.tiles_m;
+    g.group_m = gm;
+  }
   hipStream_t s = (hipStream_t)stream;
   char tag[128];
   snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d B=%d h=%d w=%d c0=%d c1=%d act=%d", M, g.N, g.K,

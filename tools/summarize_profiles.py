@@ -8,7 +8,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst), exist_ok=True)
-LAUNCHES_PER_STEP_IGEMM = 491
+DDIM_STEPS = 50   # of the kernel-trace run; DDIM-step executions are counted from the ddim_update kernel (one launch per step)
 
 
 def short(name):
@@ -23,10 +23,14 @@ if os.path.exists(ks):
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     ig = [r for r in rows if "igemm_kernel" in r["Name"]]
     ig_calls = sum(int(r["Calls"]) for r in ig)
-    execs = ig_calls / LAUNCHES_PER_STEP_IGEMM
-    lines = ["# rocprofv3 --kernel-trace --stats : python bench.py --steps 2 --warmup 1 (configs[1], 1 frame, 50 DDIM steps)",
-             f"# total kernel time {tot / 1e6:.1f} ms over {execs:.1f} DDIM-step executions = {tot / 1e6 / execs:.2f} ms/step (profiled run)",
+    execs = sum(int(r["Calls"]) for r in rows if "ddim_update" in r["Name"])
+    frames = execs / DDIM_STEPS
+    lines = ["# rocprofv3 --kernel-trace --stats : python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline (configs[1]: 1 frame, "
+             "reference-KV table pass + 50 DDIM steps + first-stage decode; includes the graph warm-up pass and the capture run)",
+             f"# total kernel time {tot / 1e6:.1f} ms over {execs} DDIM-step executions ({frames:.2f} frames) = {tot / 1e6 / frames:.1f} ms/frame, "
+             f"{tot / 1e6 / execs:.2f} ms per DDIM step incl. the per-frame table pass and decode (profiled run, kernels serialised by the tracer)",
              "# columns: total_ms, ms_per_ddim_step, calls, avg_us, percent, kernel"]
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     for r in rows[:40]:
         t = float(r["TotalDurationNs"])
         lines.append(f"{t / 1e6:10.2f} {t / 1e6 / execs:8.3f} {int(r['Calls']):8d} {float(r['AverageNs']) / 1e3:9.2f} "

@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   static_assert(STAGES == 2 || GLDS, "deep pipeline needs the direct-to-LDS loader");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
-  constexpr int AJ = BM / 32, WJ = BN / 32;  // 16-byte chunks per thread per k-tile
+  constexpr int AJ = BM / 32, WJ = (BN + 31) / 32;  // 16-byte chunks per thread per k-tile
+  // BN % 32 == 16 (the 80-wide SD tiles): the last W pass covers 16 rows = waves 0 and 1 only (a wave serves 8 rows)
+  constexpr bool W_TAIL = (BN % 32) != 0;
+  static_assert(!W_TAIL || LOADER == 2, "ragged BN is implemented for the buffer loader only");
+  static_assert(BM % 32 == 0 && BN % 16 == 0, "tile shape");
   constexpr int STAGE_BYTES = (BM + BN) * 128;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,9 +257,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       }
       const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
 #pragma unroll
-      for (int j = 0; j < WJ; ++j)
+      for (int j = 0; j < WJ; ++j) {
+        if (W_TAIL && j == WJ - 1 && wave >= 2) break;  // wave-uniform: rows 32 j + 8 wave .. + 7 lie beyond BN
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
                                                  16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
+      }
       ++kt_i;
       if (g.ksize == 3) {
         if (++tap_u == 9) {
@@ -482,15 +488,22 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 // families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
 //           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
-const float kTileEff[4] = {1.00f, 0.85f, 0.85f, 0.70f};
-const int kTileBM[4] = {128, 128, 64, 64}, kTileBN[4] = {128, 64, 128, 64};
+const float kTileEff[8] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f};
+const int kTileBM[8] = {128, 128, 64, 64, 128, 128, 64, 64}, kTileBN[8] = {128, 64, 128, 64, 80, 160, 160, 80};
 constexpr int kNumFamilies = 6;
 constexpr int kNumCfgs = 4 * kNumFamilies;
+// configs 24..27: SD-shaped tiles of the buffer loader (2 stages) -- 128x80, 128x160, 64x160, 64x80.  Every channel count of
+// SD-1.5 is a multiple of 80 (320 = 4 x 80), so these cover N exactly where the 64 / 128-wide tiles waste up to 17 %, and e.g.
+// M = 8192, N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
+constexpr int kFirstSdCfg = 24, kNumAllCfgs = 28;
 struct TileCfg {
   int bm, bn;
   float eff;
 };
-inline TileCfg cfg_of(int c) { return TileCfg{kTileBM[c & 3], kTileBN[c & 3], kTileEff[c & 3]}; }
+inline TileCfg cfg_of(int c) {
+  const int t = c >= kFirstSdCfg ? 4 + (c - kFirstSdCfg) : (c & 3);
+  return TileCfg{kTileBM[t], kTileBN[t], kTileEff[t]};
+}
 // default loader family: MD_IGEMM_LOADER = 0..4
 int g_default_loader = [] {
   const char* e = getenv("MD_IGEMM_LOADER");
@@ -561,7 +574,8 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
       if (t->m == M && t->n == N && t->k == K && t->ksize == p->ksize && t->stride == p->stride && t->ups == p->ups) {
         const bool ok_split = t->split == 1 || (p->act != MD_ACT_GEGLU && (long long)t->split * M * N * 4 <= ws_bytes);
         const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
-        if (ok_split && ok_buf) {
+        const bool ok_act = t->cfg < kFirstSdCfg || p->act != MD_ACT_GEGLU;
+        if (ok_split && ok_buf && ok_act) {
           *cfg_out = t->cfg;
           *split_out = t->split;
           return;
@@ -575,9 +589,9 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
   // the buffer-descriptor loader needs tile-uniform (tap, source): 64-channel k-tiles must not straddle either
   const bool buf_ok = ((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0);
   const int fam = (g_default_loader >= 3 && !buf_ok) ? 1 : g_default_loader;
-  for (int c = 0; c < kNumCfgs; ++c) {
+  for (int c = 0; c < kNumAllCfgs; ++c) {
     if (p->force_cfg >= 0 && c != p->force_cfg) continue;
-    if (p->force_cfg < 0 && c / 4 != fam) continue;
+    if (p->force_cfg < 0 && (c >= kNumCfgs || c / 4 != fam)) continue;
     const long long tm = (M + cfg_of(c).bm - 1) / cfg_of(c).bm, tn = (N + cfg_of(c).bn - 1) / cfg_of(c).bn;
     const long long blocks = tm * tn;
     const double rate_cu = 2.5e15 / 256.0 * 0.35 * cfg_of(c).eff;  // flop/s per CU we expect from this tile
@@ -664,6 +678,7 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
+  if (cfg >= kFirstSdCfg && (cfg >= kNumAllCfgs || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
@@ -686,6 +701,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
                      (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0, tag);
   int rc;
   switch (cfg) {
+    case 24: rc = launch_cfg<128, 80, 4, 1, 2, 2>(g, s); break;
+    case 25: rc = launch_cfg<128, 160, 2, 2, 2, 2>(g, s); break;
+    case 26: rc = launch_cfg<64, 160, 2, 2, 2, 2>(g, s); break;
+    case 27: rc = launch_cfg<64, 80, 4, 1, 2, 2>(g, s); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
     case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
     case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;

@@ -6,10 +6,10 @@ from magicdance_amd import ops
 dev = torch.device("cuda:0"); F16 = torch.float16
 ws = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
 CASES = [  # B, H, W, Cin, Cout, ks, cfg, split
-    (2, 64, 64, 320, 320, 3, 19, 1), (2, 64, 64, 320, 320, 3, 12, 1), (2, 64, 64, 320, 320, 3, 14, 1),
-    (1, 16, 16, 1280, 1280, 3, 19, 8), (1, 16, 16, 1280, 1280, 3, 15, 1),
-    (1, 8, 8, 1280, 1280, 3, 19, 8),
-    (1, 32, 32, 640, 640, 1, 15, 1), (2, 16, 16, 1280, 10240, 1, 14, 1),
+    (2, 64, 64, 320, 320, 3, 15, 1), (2, 64, 64, 320, 320, 3, 27, 1), (2, 64, 64, 320, 320, 3, 24, 1),
+    (16, 64, 64, 640, 640, 3, 12, 1), (16, 64, 64, 640, 640, 3, 25, 1),
+    (16, 64, 64, 1280, 1280, 1, 12, 1), (16, 64, 64, 1280, 1280, 1, 25, 1),
+    (1, 16, 16, 1280, 1280, 3, 15, 8),
 ]
 for (b, h, w, cin, cout, k, cfg, sp) in CASES:
     x = torch.randn(b, h * w, cin, device=dev).to(F16); wt = (torch.randn(cout, k * k * cin, device=dev) * 0.02).to(F16)

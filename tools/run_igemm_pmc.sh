@@ -1,0 +1,25 @@
+#!/bin/bash
+# cache-behaviour counters of a few isolated md_igemm shapes (GPU box only): bash tools/run_igemm_pmc.sh <dir under gpurun_out>
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+D=$R/gpurun_out/${1:-igpmc}
+mkdir -p "$D"; cd /tmp && export TMPDIR=/tmp; cd "$R"
+timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d "$D" -o l2 --output-format csv -- python tools/igemm_pmc.py > "$D/l2.log" 2>&1; echo l2 rc=$?
+timeout 200 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE -d "$D" -o l1 --output-format csv -- python tools/igemm_pmc.py > "$D/l1.log" 2>&1; echo l1 rc=$?
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES -d "$D" -o sq --output-format csv -- python tools/igemm_pmc.py > "$D/sq.log" 2>&1; echo sq rc=$?
+python - "$D" <<'PY'
+import csv, sys, collections, os
+d = sys.argv[1]
+for tag in ("l2", "l1", "sq"):
+    p = os.path.join(d, f"{tag}_counter_collection.csv")
+    if not os.path.exists(p):
+        print(tag, "missing"); continue
+    rows = list(csv.DictReader(open(p)))
+    byk = collections.OrderedDict()
+    for r in rows:
+        if "igemm_kernel" not in r["Kernel_Name"]:
+            continue
+        key = (r["Dispatch_Id"], r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60], r["Grid_Size"])
+        byk.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    for k, v in byk.items():
+        print(tag, k[1], "grid", k[2], " ".join(f"{a}={b:.3g}" for a, b in v.items()))
+PY

@@ -66,6 +66,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     out = torch.empty(B, ho * wo, nout, dtype=F16, device=dev)
     buf_ok = (c0 + c1) % 64 == 0 and c0 % 64 == 0
     cfgs = list(range(12, 16)) if buf_ok else list(range(4, 8))  # 2-stage (vmcnt(0)) loaders only, see igemm.hip
+    if buf_ok and N % 80 == 0 and act != 2:
+        cfgs += [24, 25, 26, 27]   # SD-shaped tiles (BN = 80 / 160)
     nk = (K + 63) // 64
     splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16, 24) if act != 2 and M <= 4096 and nk // s >= 2 and s * M * N * 4 <= ws.numel()]
     res = []

@@ -6,8 +6,8 @@ Public surface = the reference's for this path: ``create_model`` / ``load_state_
 All arithmetic runs in libmagicdance_hip.so (include/magicdance_hip.h); importing this package does not load it,
 using any op without it raises.
 """
-from .cldm import (ControlLDMReferenceOnlyPose, create_model, load_state_dict, instantiate_from_config,  # noqa: F401
+from .cldm import (ControlLDMReferenceOnlyPose, ControlLDMReferenceOnly, create_model, load_state_dict, instantiate_from_config,  # noqa: F401
                    DEFAULT_CONFIG)
-from .nets import ControlledUnetModelAttnPose, ControlNetReferenceOnly, ControlNet  # noqa: F401
+from .nets import ControlledUnetModelAttnPose, ControlledUnetModelAttn, ControlNetReferenceOnly, ControlNet  # noqa: F401
 
 __version__ = "0.1.0"

@@ -105,6 +105,8 @@ class DiffusionWrapper(nn.Module):
 
 
 class ControlLDMReferenceOnlyPose(nn.Module):
+    has_pose = True
+
     def __init__(self, control_key=None, only_mid_control=False, appearance_control_stage_config=None,
                  pose_control_stage_config=None, unet_config=None, first_stage_config=None, cond_stage_config=None,
                  timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3,
@@ -124,14 +126,17 @@ class ControlLDMReferenceOnlyPose(nn.Module):
         self.conditioning_key, self.v_posterior, self.use_ema = conditioning_key, v_posterior, use_ema
         self.sd_locked = True
         self.model = DiffusionWrapper(unet_config, conditioning_key)
-        self.appearance_control_model = instantiate_from_config(appearance_control_stage_config)
-        self.pose_control_model = instantiate_from_config(pose_control_stage_config)
+        self._build_control(appearance_control_stage_config, pose_control_stage_config)
         self.first_stage_model = self._optional(first_stage_config, "first_stage_model (VAE)")
         self.cond_stage_model = self._optional(cond_stage_config, "cond_stage_model (CLIP text encoder)")
         self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                linear_end=linear_end, cosine_s=cosine_s)
         self.register_buffer("logvar", torch.full(fill_value=logvar_init, size=(self.num_timesteps,)))
         self._fused = None
+
+    def _build_control(self, appearance_cfg, pose_cfg):
+        self.appearance_control_model = instantiate_from_config(appearance_cfg)
+        self.pose_control_model = instantiate_from_config(pose_cfg)
 
     @staticmethod
     def _optional(config, what):
@@ -214,7 +219,7 @@ class ControlLDMReferenceOnlyPose(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def engines(self):
-        return (self.appearance_control_model.md_engine(), self.pose_control_model.md_engine(),
+        return (self.appearance_control_model.md_engine(), self.pose_control_model.md_engine() if self.has_pose else None,
                 self.model.diffusion_model.md_engine())
 
     @torch.no_grad()
@@ -249,7 +254,7 @@ class ControlLDMReferenceOnlyPose(nn.Module):
             ref = reference_image_noisy.detach().to(device=self.device, dtype=F32).contiguous()
             banks = app.appearance(ref, app._t_dev(t, ref.shape[0]), app.context_kv(cond_txt_void))
         pose = None
-        if self.control_enabled and cond.get("c_concat") is not None and not uc:
+        if self.has_pose and self.control_enabled and cond.get("c_concat") is not None and not uc:
             hint = torch.cat(cond["c_concat"], 1)
             pose = pose_e.pose(x, pose_e.hint_features(hint), t_dev, pose_e.context_kv(cond_txt_void))
         return unet.unet(x, t_dev, unet.context_kv(cond_txt), banks=None if uc else banks, pose=pose,
@@ -264,3 +269,22 @@ class ControlLDMReferenceOnlyPose(nn.Module):
         sampler = DDIMSampler_ReferenceOnly(self)
         shape = (self.channels, self.image_size, self.image_size)
         return sampler.sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
+
+
+class ControlLDMReferenceOnly(ControlLDMReferenceOnlyPose):
+    """Stage-1 model (appearance control only): cldm/cldm.py:1055-1081 with models/cldm_v15_reference_only.yaml.  The
+    appearance net sits under ``control_model.*`` (ctor kwarg ``control_stage_config``), there is no pose ControlNet and
+    ``apply_model`` never looks at ``c_concat``.  Sampling takes the generic per-step route (same kernels; the fused
+    graph route is specific to the pose model)."""
+    has_pose = False
+
+    def __init__(self, control_key=None, only_mid_control=False, control_stage_config=None, **kw):
+        self._stage1_cfg = control_stage_config
+        super().__init__(control_key=control_key, only_mid_control=only_mid_control, **kw)
+
+    def _build_control(self, appearance_cfg, pose_cfg):
+        self.control_model = instantiate_from_config(self._stage1_cfg)
+
+    @property
+    def appearance_control_model(self):
+        return self.control_model

@@ -157,7 +157,7 @@ class DDIMSampler_ReferenceOnly(object):
 
     # ------------------------------------------------------------------ fused route
     def _fused_ok(self, c, uc, scale):
-        if uc is None or scale == 1. or not isinstance(c, dict):
+        if uc is None or scale == 1. or not isinstance(c, dict) or not getattr(self.model, "has_pose", True):
             return False
         if uc.get("image_control") is not None or c.get("overlap_sampling"):
             return False

@@ -286,6 +286,15 @@ class ControlledUnetModelAttnPose(_HotPathNet):
                                              only_mid_control, attention_mode, uc)
 
 
+class ControlledUnetModelAttn(ControlledUnetModelAttnPose):
+    """Stage-1 denoising UNet: bank 'read' only, no pose residuals (cldm.py:115-161).  Same parameters / keys; a
+    ``pose_control`` argument is accepted and ignored like the reference's."""
+
+    def forward(self, x, timesteps=None, context=None, control=None, pose_control=None,
+                only_mid_control=False, attention_mode=None, uc=False, **kwargs):
+        return self.md_engine().unet_forward(x, timesteps, context, control, None, only_mid_control, attention_mode, uc)
+
+
 class ControlNetReferenceOnly(_HotPathNet):
     """Appearance Control Model: full UNet topology, fills the attention bank (cldm.py:164-497)."""
     kind = "appearance"

@@ -87,6 +87,55 @@ def run_case(name):
     print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
 
 
+VARIANT_CASES = {
+    # name: (variant, net overrides, latent side, t probe, ddim steps) -- other branches of the same config surface
+    "small_b1_balance": ("balance", dict(model_channels=64, num_heads=2), 16, 501, 4),
+    "small_b1_stage1": ("stage1", dict(model_channels=64, num_heads=2), 16, 501, 4),
+}
+
+
+def run_variant_case(name):
+    """balance: the 2B-batched CFG branch (ddim.py:540-567; the unconditional dict carries image_control too, with a
+    DIFFERENT text context so the guidance term is not a no-op).  stage1: ControlLDMReferenceOnly + ControlledUnetModelAttn
+    from models/cldm_v15_reference_only.yaml (appearance control only)."""
+    variant, geo, side, t_probe, steps = VARIANT_CASES[name]
+    torch.manual_seed(0)
+    t0 = time.time()
+    stage1 = variant == "stage1"
+    m = ref_shim.build_reference_model(geo, image_size=side, stage1=stage1)
+    sd = {}
+    mods = [(PREFIXES["unet"], m.model.diffusion_model)]
+    mods += [("control_model.", m.control_model)] if stage1 else [(PREFIXES["app"], m.appearance_control_model),
+                                                                  (PREFIXES["pose"], m.pose_control_model)]
+    for pre, mod in mods:
+        sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
+    m.load_state_dict(sd, strict=False)
+    inp = synthetic.synth_inputs((side, side), frames=1, seed=0)
+    ctx_u = synthetic.synth_inputs((side, side), frames=1, seed=7)["ctx"]
+    ref, ctx, x_T, pose = inp["ref"], inp["ctx"], inp["x_T"], inp["pose"]
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx_u if variant == "balance" else ctx], "wonoise": True, "overlap_sampling": False}
+    if variant == "balance":
+        uc["image_control"] = [ref]
+    out = dict(geo_model_channels=geo["model_channels"], geo_num_heads=geo["num_heads"], side=side, frames=1, t_probe=t_probe,
+               steps=steps, seed=0, x_T=x_T.numpy(), ref=ref.numpy(), ctx_sum=summarize(ctx), pose_sum=summarize(pose),
+               state_keys=np.array("\n".join(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()
+                                             if k.startswith(("model.", "control_model.", "appearance_", "pose_")))))
+    t = torch.full((1,), t_probe, dtype=torch.long)
+    with torch.no_grad():
+        out["eps_c"] = m.apply_model(x_T, t, c, ref).numpy()
+        out["eps_u"] = m.apply_model(x_T, t, c, None, uc=True).numpy()
+        traj = []
+        z, _ = m.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
+                            unconditional_conditioning=uc, inpaint=None, x_T=x_T,
+                            img_callback=lambda pred_x0, i: traj.append(pred_x0.clone()))
+        out["z"] = z.numpy()
+        out["pred_x0_traj"] = torch.stack(traj).numpy()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
+
+
 VAE_CASES = {
     # name: (ddconfig overrides, latent side, batch).  Images / moments of the small cases are stored in full, the
     # SD-1.5-geometry ones as a stride-4 subsample + summary statistics.
@@ -124,5 +173,5 @@ def run_vae_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(VAE_CASES)):
-        run_vae_case(n) if n in VAE_CASES else run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(VARIANT_CASES) + list(VAE_CASES)):
+        run_vae_case(n) if n in VAE_CASES else (run_variant_case(n) if n in VARIANT_CASES else run_case(n))

@@ -97,23 +97,24 @@ def load_reference():
     return types.SimpleNamespace(**_LOADED)
 
 
-def reference_yaml_config(overrides=None):
+def reference_yaml_config(overrides=None, stage1=False):
     """The reference's own YAML (CN/models/cldm_v15_reference_only_pose.yaml) as plain dicts, with
     the three network param blocks optionally overridden (small test geometries) and CLIP/VAE
     replaced by the reference's own '__is_unconditional__' / identity escape hatches."""
     import yaml
-    path = os.path.join(REFERENCE_ROOT, "model_lib/ControlNet/models/cldm_v15_reference_only_pose.yaml")
+    path = os.path.join(REFERENCE_ROOT, "model_lib/ControlNet/models/cldm_v15_reference_only%s.yaml" % ("" if stage1 else "_pose"))
     cfg = yaml.safe_load(open(path))["model"]
     cfg["params"]["cond_stage_config"] = "__is_unconditional__"
     if overrides:
-        for blk in ("appearance_control_stage_config", "pose_control_stage_config", "unet_config"):
+        for blk in (("control_stage_config", "unet_config") if stage1 else
+                    ("appearance_control_stage_config", "pose_control_stage_config", "unet_config")):
             cfg["params"][blk]["params"].update(overrides)
     return cfg
 
 
-def build_reference_model(overrides=None, image_size=None, with_vae=False):
+def build_reference_model(overrides=None, image_size=None, with_vae=False, stage1=False):
     ref = load_reference()
-    cfg = reference_yaml_config(overrides)
+    cfg = reference_yaml_config(overrides, stage1=stage1)
     if not with_vae:
         # shrink the VAE (unused on the hot path) so construction is quick
         dd = cfg["params"]["first_stage_config"]["params"]["ddconfig"]

@@ -255,9 +255,16 @@ def unet_forward(sd, pre, cfg, x, t, ctx, banks=None, pose=None, uc=False, only_
 UNET, APP, POSE = "model.diffusion_model.", "appearance_control_model.", "pose_control_model."
 
 
-def apply_model(sd, cfg, x_noisy, t, cond, reference_image_noisy, uc=False, only_mid_control=False):
-    """cldm.py:1099-1117 (ControlLDMReferenceOnlyPose.apply_model)."""
+STAGE1_APP = "control_model."
+
+
+def apply_model(sd, cfg, x_noisy, t, cond, reference_image_noisy, uc=False, only_mid_control=False, stage1=False):
+    """cldm.py:1099-1117 (ControlLDMReferenceOnlyPose.apply_model); ``stage1``: cldm.py:1066-1077
+    (ControlLDMReferenceOnly.apply_model -- appearance net under ``control_model.``, no pose ControlNet, c_concat unused)."""
     ctx = torch.cat(cond["c_crossattn"], 1).float()
+    if stage1:
+        banks = appearance_forward(sd, STAGE1_APP, cfg, reference_image_noisy, t, ctx) if reference_image_noisy is not None else []
+        return unet_forward(sd, UNET, cfg, x_noisy, t, ctx, banks, None, uc, only_mid_control)
     ctx_void = torch.cat(cond["c_crossattn_void"], 1).float() if cond.get("c_crossattn_void") is not None else ctx
     banks = []
     if reference_image_noisy is not None:
@@ -275,8 +282,9 @@ def q_sample(ac, x0, t, noise):
     return a * x0 + b * noise
 
 
-def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record=None):
-    """ddim.py:391-516 + 519-645 ('controlnet is more important' branch :595-605, eps parameterisation,
+def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record=None, stage1=False):
+    """ddim.py:391-516 + 519-645 ('controlnet is more important' branch :595-605, or the 'balance' 2B-batched branch
+    :540-567 when the unconditional dict carries ``image_control`` too; eps parameterisation,
     eta = 0 so sigma_t = 0 and the noise term vanishes; the reference still draws it, :641).
     ``record(i, dict)`` receives eps_t / eps_uc / x_prev per step for seam-level parity."""
     ac = alphas_cumprod()
@@ -291,11 +299,17 @@ def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record
         t = torch.full((b,), int(step), dtype=torch.long)
         ref = ref0 if cond["wonoise"] else q_sample(ac, ref0, t, torch.randn_like(ref0))   # :529-535
         if uncond is None or scale == 1.0:
-            e_t = apply_model(sd, cfg, img, t, cond, ref)                                   # :537-538
+            e_t = apply_model(sd, cfg, img, t, cond, ref, stage1=stage1)                    # :537-538
             e_c = e_u = e_t
+        elif uncond.get("image_control") is not None:                                       # balance :540-567
+            c_in = {k: ([torch.cat([uncond[k][j], cond[k][j]]) for j in range(len(cond[k]))] if isinstance(cond[k], list)
+                        else cond[k]) for k in cond}
+            e_u, e_c = apply_model(sd, cfg, torch.cat([img] * 2), torch.cat([t] * 2), c_in, torch.cat([ref] * 2),
+                                   stage1=stage1).chunk(2)
+            e_t = e_u + scale * (e_c - e_u)
         else:
-            e_c = apply_model(sd, cfg, img, t, cond, ref)                                   # :603
-            e_u = apply_model(sd, cfg, img, t, cond, None, uc=True)                         # :604
+            e_c = apply_model(sd, cfg, img, t, cond, ref, stage1=stage1)                    # :603
+            e_u = apply_model(sd, cfg, img, t, cond, None, uc=True, stage1=stage1)          # :604
             e_t = e_u + scale * (e_c - e_u)                                                 # :605
         a_t = torch.full((b, 1, 1, 1), float(alphas[index]))
         a_prev = torch.full((b, 1, 1, 1), float(alphas_prev[index]))

@@ -16,20 +16,23 @@ def net_kwargs(model_channels=320, num_heads=8):
                 transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
 
 
-def build_nets(model_channels=320, num_heads=8, device="meta"):
+def build_nets(model_channels=320, num_heads=8, device="meta", stage1=False):
     kw = net_kwargs(model_channels, num_heads)
     with torch.device(device):
         unet = nets.ControlledUnetModelAttnPose(out_channels=4, **kw)
         app = nets.ControlNetReferenceOnly(out_channels=4, hint_channels=3, **kw)
+        if stage1:
+            return dict(unet=unet, app1=app)
         pose = nets.ControlNet(hint_channels=3, **kw)
     return dict(unet=unet, app=app, pose=pose)
 
 
-def synth_weights(model_channels=320, num_heads=8, seed=0, device="cpu"):
-    mods = build_nets(model_channels, num_heads, "meta")
+def synth_weights(model_channels=320, num_heads=8, seed=0, device="cpu", stage1=False):
+    """stage1: the appearance net's keys live under ``control_model.`` (models/cldm_v15_reference_only.yaml)."""
+    mods = build_nets(model_channels, num_heads, "meta", stage1)
     sd = {}
     for k, m in mods.items():
-        sd.update(synthetic.synth_state_dict(m, PREFIXES[k], seed=seed, device=device))
+        sd.update(synthetic.synth_state_dict(m, "control_model." if k == "app1" else PREFIXES[k], seed=seed, device=device))
     return sd
 
 
@@ -47,7 +50,11 @@ def case_inputs(g):
     assert np.array_equal(x_T.numpy(), g["x_T"]) and np.array_equal(ref.numpy(), g["ref"])
     c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
     uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
-    return dict(ref=ref, ctx=ctx, x_T=x_T, pose=pose, c=c, uc=uc)
+    # 'balance' variant (oracle/make_golden.py VARIANT_CASES): the unconditional dict carries the reference too, with
+    # another seeded text context so that the guidance term is not a no-op
+    ctx_u = synthetic.synth_inputs((side, side), frames=1, seed=7)["ctx"]
+    uc_balance = {"c_concat": [pose], "c_crossattn": [ctx_u], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    return dict(ref=ref, ctx=ctx, x_T=x_T, pose=pose, c=c, uc=uc, uc_balance=uc_balance)
 
 
 def summarize(t):
@@ -60,12 +67,14 @@ def head_slice(t, n=4):
     return (t[:, :n] if t.dim() == 3 else t[:, :, :1, :n]).contiguous().cpu().numpy()
 
 
-def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64):
-    """The product model (magicdance_amd.cldm.ControlLDMReferenceOnlyPose) built from the shipped YAML with the
-    golden case's geometry, loaded with the seeded synthetic weights."""
+def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64, stage1=False):
+    """The product model (magicdance_amd.cldm.ControlLDMReferenceOnlyPose, or the stage-1 ControlLDMReferenceOnly) built
+    from the shipped YAML with the golden case's geometry, loaded with the seeded synthetic weights."""
     import magicdance_amd as M
-    cfg = M.cldm.load_config(M.DEFAULT_CONFIG)["model"]
-    for blk in ("appearance_control_stage_config", "pose_control_stage_config", "unet_config"):
+    path = M.DEFAULT_CONFIG.replace("_pose.yaml", ".yaml") if stage1 else M.DEFAULT_CONFIG
+    cfg = M.cldm.load_config(path)["model"]
+    for blk in (("control_stage_config", "unet_config") if stage1 else
+                ("appearance_control_stage_config", "pose_control_stage_config", "unet_config")):
         cfg["params"][blk]["params"].update(model_channels=model_channels, num_heads=num_heads)
     cfg["params"]["first_stage_config"] = "__is_first_stage__"
     cfg["params"]["cond_stage_config"] = "__is_unconditional__"
@@ -75,9 +84,9 @@ def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", imag
     model = model.to_empty(device=device)
     model.register_schedule(timesteps=1000, linear_start=cfg["params"]["linear_start"], linear_end=cfg["params"]["linear_end"])
     model.logvar = torch.zeros(1000)
-    sd = synth_weights(model_channels, num_heads, seed=seed, device="cpu")
+    sd = synth_weights(model_channels, num_heads, seed=seed, device="cpu", stage1=stage1)
     missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not unexpected and all(not k.startswith(("model.", "appearance", "pose")) for k in missing), (missing[:5], unexpected[:5])
+    assert not unexpected and all(not k.startswith(("model.", "appearance", "pose", "control_model")) for k in missing), (missing[:5], unexpected[:5])
     return model.to(device).eval()
 
 

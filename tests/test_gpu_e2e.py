@@ -151,3 +151,26 @@ def test_frames_are_independent(dev):
         sl = lambda d: {k: ([v[0][f:f + 1]] if isinstance(v, list) else v) for k, v in d.items()}  # noqa: E731
         zf, _ = model.sample_log(cond=sl(c), batch_size=1, unconditional_conditioning=sl(uc), x_T=x_T[f:f + 1], **kw)
         assert _rel(zf.cpu().numpy(), z[f:f + 1].cpu().numpy(), f"frame {f} alone vs in batch") <= 5e-3
+
+
+@pytest.mark.parametrize("name", ["small_b1_balance", "small_b1_stage1"])
+def test_variants_match_reference_golden(dev, name):
+    """the 'balance' CFG branch (2B-batched pass with the reference attention on both halves, ddim.py:540-567)
+    and the stage-1 model (ControlLDMReferenceOnly + ControlledUnetModelAttn from cldm_v15_reference_only.yaml), both through
+    the generic per-step sampler route, against goldens of the unmodified reference."""
+    g = H.load_golden(name)
+    stage1 = name.endswith("stage1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device=dev,
+                              image_size=int(g["side"]), stage1=stage1)
+    inp = H.case_inputs(g)
+    c, uc = _to_dev(inp["c"], dev), _to_dev(inp["uc"] if stage1 else inp["uc_balance"], dev)
+    x_T, ref = inp["x_T"].to(dev), inp["ref"].to(dev)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long, device=dev)
+    assert _rel(model.apply_model(x_T, t, c, ref).cpu().numpy(), g["eps_c"], f"{name} eps_c vs golden") <= TOL_EPS
+    assert _rel(model.apply_model(x_T, t, c, None, uc=True).cpu().numpy(), g["eps_u"], f"{name} eps_u vs golden") <= TOL_EPS
+    traj = []
+    z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
+                            unconditional_conditioning=uc, inpaint=None, x_T=x_T,
+                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
+    assert _rel(z.cpu().numpy(), g["z"], f"{name} z({int(g['steps'])} steps) vs golden") <= TOL_Z
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], f"{name} pred_x0 trajectory vs golden") <= TOL_Z

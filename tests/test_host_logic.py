@@ -131,3 +131,21 @@ def test_vae_engine_host_logic_matches_reference_golden(monkeypatch, name):
     torch.manual_seed(3)
     ref = post.mean + post.std * torch.randn(post.mean.shape)
     assert torch.equal(s, ref) and torch.equal(post.mode(), post.mean)
+
+
+@pytest.mark.parametrize("name", ["small_b1_balance", "small_b1_stage1"])
+def test_variant_host_logic_matches_reference_golden(monkeypatch, name):
+    """'balance' CFG branch (2B-batched pass, generic sampler route) and the stage-1 model class / YAML, emulated kernels."""
+    hip_emulator.install(monkeypatch)
+    g = H.load_golden(name)
+    stage1 = name.endswith("stage1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
+                              image_size=int(g["side"]), stage1=stage1)
+    inp = H.case_inputs(g)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long)
+    assert _rel(model.apply_model(inp["x_T"], t, inp["c"], inp["ref"]).numpy(), g["eps_c"]) <= 5e-3
+    assert _rel(model.apply_model(inp["x_T"], t, inp["c"], None, uc=True).numpy(), g["eps_u"]) <= 5e-3
+    z, _ = model.sample_log(cond=inp["c"], batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                            unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"] if stage1 else inp["uc_balance"],
+                            inpaint=None, x_T=inp["x_T"])
+    assert _rel(z.numpy(), g["z"]) <= 1e-2

@@ -52,3 +52,34 @@ def test_schedule_constants():
     assert abs(float(ac[0]) - 0.99915) < 1e-6 and abs(float(ac[999]) - 0.0046602) < 1e-6
     sig, a, ap = R.make_ddim_sampling_parameters(ac, ts, 0.0)
     assert float(np.abs(sig).max()) == 0.0 and float(ap[0]) == float(ac[0]) and float(ap[1]) == float(a[0])
+
+
+@pytest.mark.parametrize("name", ["small_b1_balance", "small_b1_stage1"])
+def test_restatement_variants_match_reference_golden(name):
+    """Other branches of the same config surface: the 2B-batched 'balance' CFG branch (ddim.py:540-567) and the
+    stage-1 model (ControlLDMReferenceOnly / ControlledUnetModelAttn, models/cldm_v15_reference_only.yaml)."""
+    g = H.load_golden(name)
+    stage1 = name.endswith("stage1")
+    mc, nh = int(g["geo_model_channels"]), int(g["geo_num_heads"])
+    sd = H.synth_weights(mc, nh, seed=int(g["seed"]), stage1=stage1)
+    cfg = R.Cfg(model_channels=mc, num_heads=nh)
+    inp = H.case_inputs(g)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long)
+    with torch.no_grad():
+        e_c = R.apply_model(sd, cfg, inp["x_T"], t, inp["c"], inp["ref"], stage1=stage1)
+        e_u = R.apply_model(sd, cfg, inp["x_T"], t, inp["c"], None, uc=True, stage1=stage1)
+        np.testing.assert_allclose(e_c.numpy(), g["eps_c"], atol=5e-5, rtol=1e-4)
+        np.testing.assert_allclose(e_u.numpy(), g["eps_u"], atol=5e-5, rtol=1e-4)
+        traj = []
+        z = R.ddim_sample(sd, cfg, inp["c"], inp["uc"] if stage1 else inp["uc_balance"], inp["x_T"], steps=int(g["steps"]),
+                          eta=0.0, scale=7.0, record=lambda i, d: traj.append(d["pred_x0"]), stage1=stage1)
+    scale = float(np.abs(g["z"]).max())
+    assert float(np.abs(z.numpy() - g["z"]).max()) <= 2e-5 * max(1.0, scale)
+    np.testing.assert_allclose(torch.stack(traj).numpy(), g["pred_x0_traj"], atol=2e-5 * max(1.0, scale), rtol=1e-4)
+
+
+def test_stage1_container_has_the_reference_state_dict_layout():
+    g = H.load_golden("small_b1_stage1")
+    mine = H.synth_weights(int(g["geo_model_channels"]), int(g["geo_num_heads"]), stage1=True)
+    want = dict(line.rsplit(":", 1) for line in str(g["state_keys"]).split("\n"))
+    assert {k: str(tuple(v.shape)) for k, v in mine.items()} == want

@@ -179,18 +179,40 @@ class DDIMSampler_ReferenceOnly(object):
         with torch.cuda.stream(st.stream):
             table = os.environ.get("MD_BANK_MODE", "table") != "inline"
             st.prepare(c, img, self, scale, table_mode=table)
-            if table:
-                st.compute_bank_rows(range(total))
-            for i in range(total):
-                st.step()
-                index = total - i - 1
-                if callback:
-                    callback(i)
-                if img_callback:
-                    img_callback(st.pred_x0.clone(), i)
-                if index % log_every_t == 0 or index == total - 1:
-                    intermediates["x_inter"].append(st.x.clone())
-                    intermediates["pred_x0"].append(st.pred_x0.clone())
+            # The table pass runs AHEAD of the loop on its own stream (own arena / workspaces): step i only needs row i,
+            # and the big-batch appearance GEMMs of chunk k+1 fill the CUs that the small launches of chunk k's steps
+            # leave idle.  Host order = chunk k+1's launches, then chunk k's graph launches.
+            chunks = st.bank_chunks(total) if table else [(0, total)]
+            overlap = table and os.environ.get("MD_TABLE_OVERLAP", "1") != "0"
+
+            def enqueue(k):
+                if not overlap:
+                    st.compute_bank_rows(range(*chunks[k]))
+                    return None
+                with torch.cuda.stream(st.table_stream):
+                    st.compute_bank_rows(range(*chunks[k]))
+                    ev = torch.cuda.Event()
+                    ev.record(st.table_stream)
+                return ev
+
+            if overlap:
+                st.table_stream.wait_stream(st.stream)   # the previous frame's steps are done with the table; inputs are in place
+            ev = enqueue(0) if table else None
+            for k, (r0, r1) in enumerate(chunks):
+                ev_next = enqueue(k + 1) if table and k + 1 < len(chunks) else None
+                if ev is not None:
+                    st.stream.wait_event(ev)
+                ev = ev_next
+                for i in range(r0, r1):
+                    st.step()
+                    index = total - i - 1
+                    if callback:
+                        callback(i)
+                    if img_callback:
+                        img_callback(st.pred_x0.clone(), i)
+                    if index % log_every_t == 0 or index == total - 1:
+                        intermediates["x_inter"].append(st.x.clone())
+                        intermediates["pred_x0"].append(st.pred_x0.clone())
             out = st.x.clone()
         caller.wait_stream(st.stream)
         return out, intermediates
@@ -219,13 +241,15 @@ class FusedStepRunner:
         self.graph = None
         self.use_graph = True
         self.table_mode = False
-        self.stream = torch.cuda.Stream(device=model.device)
+        # (a high-priority step stream was measured SLOWER: 2.05 vs 2.23 frames/s with the table pass overlapped)
+        self.stream = torch.cuda.Stream(device=model.device, priority=int(os.environ.get("MD_STEP_PRIORITY", "0")))
         # independent network passes of one step run on forked streams inside the captured graph:
         #   0 serial | 1 appearance || pose, then UNet(cond+uncond batched) | 2 appearance || pose || UNet-uncond, then UNet-cond
         #   3 appearance || pose || UNet, the UNet waiting per bank entry (event) and for the pose residuals at its middle block
         self.overlap = int(os.environ.get("MD_OVERLAP", "3"))
         self.bank_events = None
         self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
+        self.table_stream = torch.cuda.Stream(device=model.device)      # the table pass overlaps the first steps of the loop
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
 
     def _same_rows(self, t):
@@ -324,35 +348,48 @@ class FusedStepRunner:
             out += [self.bank_table[tk + r0 * lk:tk + r1 * lk], self.bank_table[tv + r0 * lv:tv + r1 * lv]]
         return out
 
+    def bank_chunks(self, S):
+        """[(r0, r1)] row blocks of one batched appearance pass each."""
+        per = max(1, self.bank_chunk // self.ref.shape[0])
+        return [(r0, min(S, r0 + per)) for r0 in range(0, S, per)]
+
     def compute_bank_rows(self, rows):
         """Fill the reference-KV table for DDIM steps ``rows`` (indices into the flipped timestep order): the appearance
         net runs on ``bank_chunk`` timesteps per pass (sample = (step, ref) pair, per-sample time embedding), then the
-        UNet's to_k / to_v project each of the 16 bank tensors for the whole chunk straight into the table."""
-        from .engine import Act
+        UNet's to_k / to_v project each of the 16 bank tensors for the whole chunk straight into the table.
+        Runs on the current stream with its own arena and split-K workspaces, so it may overlap a step graph that reads
+        rows already finished."""
+        from .engine import Act, get_arena
         app, _, unet = self.model.engines()
         rows = list(rows)
         bref = self.ref.shape[0]
         per = max(1, self.bank_chunk // bref)
-        i = 0
-        while i < len(rows):
-            j = i + 1
-            while j < len(rows) and j - i < per and rows[j] == rows[j - 1] + 1:
-                j += 1
-            r0, tc = rows[i], j - i
-            i = j
-            nb = tc * bref
-            if self._bank_tmp is None or self._bank_tmp[0] < nb:
-                self._bank_tmp = (per * bref, [torch.empty((per * bref, n, c), dtype=F16, device=self.x.device)
-                                               for (_, _, _, _, n, c, _) in self.bank_geo])
-            tmp = [Act(t[:nb], nb, 1, t.shape[1], t.shape[2]) for t in self._bank_tmp[1]]
-            app.arena.reset()
-            t_dev = self.ts_table[r0:r0 + tc, 0].repeat_interleave(bref).contiguous()
-            x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
-            app.appearance(x, t_dev, self.kv_app, bank_out=tmp)
-            for e, (tk, tv, _, _, n, c, ldv) in enumerate(self.bank_geo):
-                lk, lv = bref * n * c, bref * c * ldv
-                unet.project_bank(e, tmp[e], self.bank_table[tk + r0 * lk:tk + (r0 + tc) * lk].view(nb, n, c),
-                                  self.bank_table[tv + r0 * lv:tv + (r0 + tc) * lv].view(nb, c, ldv))
+        step_arena, app.arena = app.arena, get_arena(self.x.device, "table")
+        app.ws_slot, unet.ws_slot = 3, 3
+        try:
+            i = 0
+            while i < len(rows):
+                j = i + 1
+                while j < len(rows) and j - i < per and rows[j] == rows[j - 1] + 1:
+                    j += 1
+                r0, tc = rows[i], j - i
+                i = j
+                nb = tc * bref
+                if self._bank_tmp is None or self._bank_tmp[0] < nb:
+                    self._bank_tmp = (per * bref, [torch.empty((per * bref, n, c), dtype=F16, device=self.x.device)
+                                                   for (_, _, _, _, n, c, _) in self.bank_geo])
+                tmp = [Act(t[:nb], nb, 1, t.shape[1], t.shape[2]) for t in self._bank_tmp[1]]
+                app.arena.reset()
+                t_dev = self.ts_table[r0:r0 + tc, 0].repeat_interleave(bref).contiguous()
+                x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
+                app.appearance(x, t_dev, self.kv_app, bank_out=tmp)
+                for e, (tk, tv, _, _, n, c, ldv) in enumerate(self.bank_geo):
+                    lk, lv = bref * n * c, bref * c * ldv
+                    unet.project_bank(e, tmp[e], self.bank_table[tk + r0 * lk:tk + (r0 + tc) * lk].view(nb, n, c),
+                                      self.bank_table[tv + r0 * lv:tv + (r0 + tc) * lv].view(nb, c, ldv))
+        finally:
+            app.arena = step_arena
+            app.ws_slot, unet.ws_slot = 0, 0
 
     def _launch_sequence(self):
         """One DDIM step as a fixed launch sequence on fixed addresses."""

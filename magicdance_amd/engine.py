@@ -76,8 +76,10 @@ class Arena:
 _ARENAS = {}
 
 
-def get_arena(device):
-    key = str(device)
+def get_arena(device, name=""):
+    """One bump arena per (device, name): "" = the per-step / per-call activations; "table" = the reference-KV table pass,
+    which runs on its own stream concurrently with the step graph and must not share addresses with it."""
+    key = str(device) + name
     if key not in _ARENAS:
         _ARENAS[key] = Arena(device)
     return _ARENAS[key]

@@ -75,6 +75,15 @@ typedef struct {
   int64_t ws_bytes;
   int32_t force_cfg;       /* -1 auto; otherwise tile config index (tests / tuning) */
   int32_t force_splitk;    /* 0 auto; otherwise number of K splits */
+  /* LayerNorm folded into the GEMM (BasicTransformerBlock: norm1 -> to_q|k|v, norm2 -> to_q, norm3 -> GEGLU proj,
+   * ldm/modules/attention.py:278-320): the rows of A are normalised on the fly,
+   *   out[m][n] = rstd_m * (sum_k a[m][k] w[n][k] - mu_m * ln_s1[n]) + ln_s0[n],
+   * with w pre-multiplied by gamma, ln_s1[n] = sum_k w[n][k], ln_s0[n] = sum_k beta_k W[n][k] + bias[n] (fp32 [N]), mu / rstd
+   * the mean / 1/sqrt(var + ln_eps) of row m over K.  Requires ksize 1, one source, c0 % 64 == 0, bias NULL, no split-K
+   * (the row statistics are accumulated inside the k-loop).  NULL ln_s1 = plain GEMM. */
+  const float* ln_s1;
+  const float* ln_s0;
+  float ln_eps;
   int32_t asym_pad;        /* 1: no padding on the top/left side, taps of output (oy, ox) start at source (stride*oy,
                             * stride*ox) and run off the bottom/right edge into zeros: the VAE encoder's Downsample,
                             * F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (ldm/modules/diffusionmodules/model.py:80-84) */

@@ -47,6 +47,10 @@ struct IgemmArgs {
   int n_tr_begin;
   int ld_t;
   float* ws;
+  // LayerNorm folded into the GEMM (A rows are normalised on the fly): out = rstd_m (acc - mu_m s1[n]) + s0[n]
+  const float* ln_s1;
+  const float* ln_s0;
+  float ln_eps, ln_inv_k;
   int dbg;  // MD_IGEMM_DEBUG bit mask (component timing only, results are garbage): 1 no MFMA, 2 no LDS reads + MFMA, 4 no k-loop loads
 };
 
@@ -104,13 +108,14 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 // the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
 //   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
 //   MFMAs on the landed stage.  Tiles past the end are fetched from the zero page so the outstanding count is constant.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
   constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
   constexpr bool BUF = LOADER == 2;    // buffer_load ... lds with hardware out-of-range -> 0 and 32-bit offsets
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   static_assert(STAGES == 2 || GLDS, "deep pipeline needs the direct-to-LDS loader");
+  static_assert(!LN || (LOADER == 2 && STAGES == 2), "LayerNorm folding is instantiated for the 2-stage buffer loader");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int AJ = BM / 32, WJ = (BN + 31) / 32;  // 16-byte chunks per thread per k-tile
@@ -329,6 +334,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // LN: per-lane partial sum / sum of squares of the A rows this lane reads as MFMA operands (row i*16+lr, k-chunks lg and
+  // 4+lg of every 64-wide tile = a quarter of K); the four lg lanes are combined after the k-loop.
+  [[maybe_unused]] float ln_sum[MF], ln_sq[MF];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
+  }
+
   auto compute_tile = [&](int stage) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Ws = As + BM * 128;
@@ -365,6 +378,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       for (int i = 0; i < NF; ++i) {
         const int row = wn * WTN + i * 16 + lr;
         wf[i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ (row & 7)) << 4));
+      }
+      if constexpr (LN) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const h2v p = {af[i][2 * e], af[i][2 * e + 1]};
+            ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
+            ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i)
@@ -419,6 +445,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
+  if constexpr (LN) {
+    // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
+    // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+      float sm = ln_sum[j], sq = ln_sq[j];
+      sm += __shfl_xor(sm, 16, 64);
+      sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const float mu = sm * g.ln_inv_k;
+      const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_k - mu * mu, 0.f) + g.ln_eps);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int n = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4);
+        const f4 s1 = *reinterpret_cast<const f4*>(g.ln_s1 + n), s0 = *reinterpret_cast<const f4*>(g.ln_s0 + n);
+        acc[i][j] = rstd * (acc[i][j] - mu * s1) + s0;
+      }
+    }
+  }
   if (g.splitk > 1) {
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
@@ -510,19 +556,25 @@ int g_default_loader = [] {
   return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
 }();
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES>
+template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES>),
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
+}
+
+// the 2-stage buffer-loader tiles exist with and without the folded LayerNorm
+template <int BM, int BN, int WMv, int WNv>
+int launch_buf2(const IgemmArgs& g, hipStream_t s) {
+  return g.ln_s1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, true>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false>(g, s);
 }
 
 void fast_div_magic(unsigned d, unsigned* mul, unsigned* sh) {
@@ -538,6 +590,8 @@ int validate(const md_igemm_params* p) {
   if (p->stride != 1 && p->stride != 2) return MD_ERR_UNSUPPORTED;
   if (p->ups && (p->ksize != 3 || p->stride != 1)) return MD_ERR_UNSUPPORTED;
   if (p->asym_pad && (p->ksize != 3 || p->ups)) return MD_ERR_UNSUPPORTED;
+  if ((p->ln_s1 != nullptr) != (p->ln_s0 != nullptr)) return MD_ERR_BAD_ARG;
+  if (p->ln_s1 && (p->ksize != 1 || p->c1 != 0 || (p->c0 & 63) || p->bias || p->stride != 1 || !(p->ln_eps > 0.f))) return MD_ERR_UNSUPPORTED;
   if (p->c0 <= 0 || (p->c0 & 7) || p->c1 < 0 || (p->c1 & 7)) return MD_ERR_BAD_ARG;
   if ((p->c1 > 0) != (p->a1 != nullptr)) return MD_ERR_BAD_ARG;
   if (p->n <= 0 || (p->n & 3) || (p->ld_out & 3)) return MD_ERR_BAD_ARG;
@@ -575,7 +629,8 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
         const bool ok_split = t->split == 1 || (p->act != MD_ACT_GEGLU && (long long)t->split * M * N * 4 <= ws_bytes);
         const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
         const bool ok_act = t->cfg < kFirstSdCfg || p->act != MD_ACT_GEGLU;
-        if (ok_split && ok_buf && ok_act) {
+        const bool ok_ln = !p->ln_s1 || (t->split == 1 && t->cfg >= 12);
+        if (ok_split && ok_buf && ok_act && ok_ln) {
           *cfg_out = t->cfg;
           *split_out = t->split;
           return;
@@ -598,7 +653,7 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
     for (int s = 1; s <= 32; s = (s < 4 ? s + 1 : s * 2)) {
       if (p->force_splitk > 0 && s != p->force_splitk) continue;
       if (s > 1) {
-        if (p->act == MD_ACT_GEGLU) break;
+        if (p->act == MD_ACT_GEGLU || p->ln_s1) break;
         if ((long long)s * M * N * 4 > ws_bytes) break;
         if (nk / s < 4) break;
       }
@@ -668,6 +723,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.n_tr_begin = p->n_tr_begin;
   g.ld_t = p->ld_t;
   g.ws = (float*)p->ws;
+  g.ln_s1 = p->ln_s1;
+  g.ln_s0 = p->ln_s0;
+  g.ln_eps = p->ln_eps;
+  g.ln_inv_k = 1.0f / (float)g.K;
   static const int dbg = [] {
     const char* e = getenv("MD_IGEMM_DEBUG");
     return e ? atoi(e) : 0;
@@ -679,6 +738,7 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
   if (cfg >= kFirstSdCfg && (cfg >= kNumAllCfgs || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
+  if (p->ln_s1 && (split > 1 || !((cfg >= 12 && cfg < 16) || cfg >= kFirstSdCfg))) return MD_ERR_UNSUPPORTED;
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
@@ -701,10 +761,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
                      (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0, tag);
   int rc;
   switch (cfg) {
-    case 24: rc = launch_cfg<128, 80, 4, 1, 2, 2>(g, s); break;
-    case 25: rc = launch_cfg<128, 160, 2, 2, 2, 2>(g, s); break;
-    case 26: rc = launch_cfg<64, 160, 2, 2, 2, 2>(g, s); break;
-    case 27: rc = launch_cfg<64, 80, 4, 1, 2, 2>(g, s); break;
+    case 24: rc = launch_buf2<128, 80, 4, 1>(g, s); break;
+    case 25: rc = launch_buf2<128, 160, 2, 2>(g, s); break;
+    case 26: rc = launch_buf2<64, 160, 2, 2>(g, s); break;
+    case 27: rc = launch_buf2<64, 80, 4, 1>(g, s); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
     case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
     case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;
@@ -717,10 +777,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
     case 9: rc = launch_cfg<128, 64, 2, 2, 1, 4>(g, s); break;
     case 10: rc = launch_cfg<64, 128, 2, 2, 1, 4>(g, s); break;
     case 11: rc = launch_cfg<64, 64, 2, 2, 1, 4>(g, s); break;
-    case 12: rc = launch_cfg<128, 128, 2, 2, 2, 2>(g, s); break;
-    case 13: rc = launch_cfg<128, 64, 2, 2, 2, 2>(g, s); break;
-    case 14: rc = launch_cfg<64, 128, 2, 2, 2, 2>(g, s); break;
-    case 15: rc = launch_cfg<64, 64, 2, 2, 2, 2>(g, s); break;
+    case 12: rc = launch_buf2<128, 128, 2, 2>(g, s); break;
+    case 13: rc = launch_buf2<128, 64, 2, 2>(g, s); break;
+    case 14: rc = launch_buf2<64, 128, 2, 2>(g, s); break;
+    case 15: rc = launch_buf2<64, 64, 2, 2>(g, s); break;
     case 16: rc = launch_cfg<128, 128, 2, 2, 2, 3>(g, s); break;
     case 17: rc = launch_cfg<128, 64, 2, 2, 2, 3>(g, s); break;
     case 18: rc = launch_cfg<64, 128, 2, 2, 2, 3>(g, s); break;

@@ -74,6 +74,7 @@ class Arena:
 
 
 _ARENAS = {}
+_FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
 
 
 def get_arena(device, name=""):
@@ -125,6 +126,18 @@ def pack_geglu(w, b, device):
     ba, bg = b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)
     bp = torch.stack([ba, bg], dim=1).reshape(2 * half)
     return _h(wp, device), _f(bp, device)
+
+
+def fold_layernorm(w, b, gamma, beta, device):
+    """LayerNorm folded into the Linear that consumes it (md_igemm ln_*): W' = W diag(gamma) in fp16, s1[n] = sum_k W'[n][k]
+    (of the ROUNDED fp16 weights the kernel multiplies with), s0[n] = sum_k beta_k W[n][k] + b[n]."""
+    w = w.detach().to(device=device, dtype=F32)
+    wl = (w * gamma.detach().to(device=device, dtype=F32)[None, :]).to(F16).contiguous()
+    s1 = wl.float().sum(1)
+    s0 = w @ beta.detach().to(device=device, dtype=F32)
+    if b is not None:
+        s0 = s0 + b.detach().to(device=device, dtype=F32)
+    return wl, s1.contiguous(), s0.contiguous()
 
 
 class Act:
@@ -218,6 +231,17 @@ class NetEngine:
                 t["o2_w"], t["o2_b"] = _h(a2.to_out[0].weight, d), _f(a2.to_out[0].bias, d)
                 t["ff1_w"], t["ff1_b"] = pack_geglu(blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach(), d)
                 t["ff2_w"], t["ff2_b"] = _h(blk.ff.net[2].weight, d), _f(blk.ff.net[2].bias, d)
+                if c % 64 == 0 and _FOLD_LN:
+                    # LayerNorm folded into its consumer GEMM (one launch fewer per LayerNorm, no fp16 round trip of LN(x))
+                    qkv = torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)
+                    t["qkv_ln"] = fold_layernorm(qkv, None, blk.norm1.weight, blk.norm1.bias, d)
+                    t["q2_ln"] = fold_layernorm(a2.to_q.weight, None, blk.norm2.weight, blk.norm2.bias, d)
+                    wl, s1, s0 = fold_layernorm(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, blk.norm3.weight,
+                                                blk.norm3.bias, d)
+                    half = wl.shape[0] // 2   # same 16-row a/gate interleave as pack_geglu, applied to W', s1 and s0
+                    il = lambda v: torch.stack([v[:half].reshape(half // 16, 16, *v.shape[1:]),  # noqa: E731
+                                                v[half:].reshape(half // 16, 16, *v.shape[1:])], 1).reshape(v.shape).contiguous()
+                    t["ff1_ln"] = (il(wl), il(s1), il(s0))
                 blocks.append(t)
             s["blocks"] = blocks
             return s
@@ -266,7 +290,7 @@ class NetEngine:
         return buf
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
-             out_f32=False, out=None):
+             out_f32=False, out=None, ln=None):
         """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act."""
         hin, win = x.h, x.w
         if ups:
@@ -281,7 +305,7 @@ class NetEngine:
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
-                  out_f32=out_f32, ws=self._ws())
+                  out_f32=out_f32, ws=self._ws(), ln=ln)
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
         return Act(out, x.b, hout, wout, nout)
 
@@ -411,13 +435,17 @@ class NetEngine:
                 if len(banks) == self._write_stop_at:
                     return None  # last bank entry written: the appearance net has no other output (cldm.py:497)
             else:
-                n1 = self.ln(t, blk["ln1"])
+                n1 = None if "qkv_ln" in blk else self.ln(t, blk["ln1"])
             # fused q|k projection (token-major) + V^T
             qk = a.alloc((b, n, 2 * c), F16)
             vt = a.alloc((b, c, ldv), F16, zero=(ldv != n))
-            tok = Act(n1.t, b, 1, n, c)
-            ops.igemm(tok.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
-                      out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws())
+            if n1 is None:   # norm1 folded into the projection
+                wl, s1, s0 = blk["qkv_ln"]
+                ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
+                          n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), ln=(s1, s0, 1e-5))
+            else:
+                ops.igemm(n1.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
+                          out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws())
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
@@ -441,8 +469,12 @@ class NetEngine:
                                  vt0_bs=c * ldv, seg1=seg1, n1_batches=n1b)
             t = self.conv(Act(att, b, 1, n, c), blk["o1_w"], c, k=1, bias=blk["o1_b"], res=Act(t.t, b, 1, n, c))
             # cross attention to the text context (attention.py:318)
-            n2 = self.ln(t, blk["ln2"])
-            q2 = self.conv(Act(n2.t, b, 1, n, c), blk["q2_w"], c, k=1)
+            if "q2_ln" in blk:
+                wl, s1, s0 = blk["q2_ln"]
+                q2 = self.conv(Act(t.t, b, 1, n, c), wl, c, k=1, ln=(s1, s0, 1e-5))
+            else:
+                n2 = self.ln(t, blk["ln2"])
+                q2 = self.conv(Act(n2.t, b, 1, n, c), blk["q2_w"], c, k=1)
             kc, vtc, bc, tk, ldvc = ctx_kv[ctx_idx[0]]
             ctx_idx[0] += 1
             assert bc == 1 or bc == b, "context batch must be 1 or match the sample batch"
@@ -450,8 +482,12 @@ class NetEngine:
                                   vt0_bs=(0 if bc == 1 else c * ldvc))
             t = self.conv(Act(att2, b, 1, n, c), blk["o2_w"], c, k=1, bias=blk["o2_b"], res=Act(t.t, b, 1, n, c))
             # GEGLU feed-forward (attention.py:50-77, 319)
-            n3 = self.ln(t, blk["ln3"])
-            ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
+            if "ff1_ln" in blk:
+                wl, s1, s0 = blk["ff1_ln"]
+                ff = self.conv(Act(t.t, b, 1, n, c), wl, 8 * c, k=1, act=MD_ACT_GEGLU, ln=(s1, s0, 1e-5))
+            else:
+                n3 = self.ln(t, blk["ln3"])
+                ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
             t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c))
         t = Act(t.t, b, x.h, x.w, c)
         return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x)

@@ -23,8 +23,8 @@ RECORD = None
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False):
-    """See md_igemm.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None):
+    """See md_igemm.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
     p.a0, p.a1, p.c0, p.c1 = _p(a0), _p(a1), c0, c1
@@ -38,10 +38,12 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
     p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
     p.force_cfg, p.force_splitk, p.asym_pad = force_cfg, force_splitk, int(asym_pad)
+    if ln is not None:
+        p.ln_s1, p.ln_s0, p.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
-        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws)))
+        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln)))
     return out
 
 

@@ -19,7 +19,7 @@ def _mem(t, size, stride):
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False):
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None):
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -36,6 +36,13 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     assert y.shape[2] == hout and y.shape[3] == wout, (y.shape, hout, wout)
     tokens = hout * wout
     y = y.permute(0, 2, 3, 1).reshape(batch, tokens, n)
+    if ln is not None:   # folded LayerNorm: out = rstd (acc - mu s1) + s0 with the row statistics of the (fp16) A rows
+        s1, s0, eps = ln
+        assert ksize == 1 and a1 is None and bias is None
+        rows = xs[0].reshape(batch, tokens, c0)
+        mu = rows.mean(-1, keepdim=True)
+        rstd = torch.rsqrt(rows.var(-1, unbiased=False, keepdim=True) + eps)
+        y = rstd * (y - mu * _mem(s1, (n,), (1,))) + _mem(s0, (n,), (1,))
     if bias is not None:
         if bias_batch_stride:
             y = y + _mem(bias, (batch, 1, n), (bias_batch_stride, 0, 1))

@@ -340,3 +340,55 @@ def test_gather_rows(dev):
     ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), None, 1, dst)
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu(), torch.cat([t[1] for t in tabs]))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 320, 960), (1, 64, 1280, 1280), (2, 1000, 640, 640), (1, 77, 64, 128)])
+@pytest.mark.parametrize("cfg", [-1, 12, 15, 24, 26, 27])
+def test_igemm_folded_layernorm(dev, shape, cfg):
+    """md_igemm ln_*: LayerNorm(x) W^T + b with gamma folded into W and the row statistics accumulated in the k-loop,
+    against F.layer_norm + F.linear (attention.py norm1/2/3 -> to_q|k|v / to_q / GEGLU proj)."""
+    from magicdance_amd import ops, engine
+    b, tokens, c, n = shape
+    x = _rand((b, tokens, c), 1, dev) * 2.0 + 0.7          # non-zero mean: the mu s1 correction matters
+    w = _rand((n, c), 2, dev, c ** -0.5)
+    bias = _rand((n,), 3, dev, 0.1)
+    gamma = 1.0 + _rand((c,), 4, dev, 0.2)
+    beta = _rand((c,), 5, dev, 0.2)
+    x16 = x.to(F16)
+    ref = F.linear(F.layer_norm(x16.float(), (c,), gamma, beta, 1e-5), w, bias)
+    wl, s1, s0 = engine.fold_layernorm(w, bias, gamma, beta, dev)
+    out = torch.empty((b, tokens, n), dtype=F16, device=dev)
+    ops.igemm(x16, wl, n, batch=b, hin=1, win=tokens, hout=1, wout=tokens, c0=c, out=out, ln=(s1, s0, 1e-5), force_cfg=cfg)
+    assert _err(out, ref) <= 6e-3 * max(1.0, float(ref.abs().max())), (shape, cfg)
+
+
+def test_igemm_folded_layernorm_geglu_and_transposed(dev):
+    """the two epilogues the folded LayerNorm meets in a transformer block: GEGLU (norm3 -> ff.net.0) and the V^T store."""
+    from magicdance_amd import ops, engine
+    b, tokens, c = 2, 256, 320
+    x16 = (_rand((b, tokens, c), 1, dev) + 0.3).to(F16)
+    gamma, beta = 1.0 + _rand((c,), 4, dev, 0.2), _rand((c,), 5, dev, 0.2)
+    xn = F.layer_norm(x16.float(), (c,), gamma, beta, 1e-5)
+    # GEGLU
+    w = _rand((8 * c, c), 2, dev, c ** -0.5)
+    bias = _rand((8 * c,), 3, dev, 0.1)
+    y = F.linear(xn, w, bias)
+    ref = y[..., :4 * c] * F.gelu(y[..., 4 * c:])
+    wl, s1, s0 = engine.fold_layernorm(w, bias, gamma, beta, dev)
+    half = 4 * c
+    il = lambda v: torch.stack([v[:half].reshape(half // 16, 16, *v.shape[1:]),  # noqa: E731
+                                v[half:].reshape(half // 16, 16, *v.shape[1:])], 1).reshape(v.shape).contiguous()
+    out = torch.empty((b, tokens, 4 * c), dtype=F16, device=dev)
+    ops.igemm(x16, il(wl), 8 * c, batch=b, hin=1, win=tokens, hout=1, wout=tokens, c0=c, out=out, ld_out=4 * c,
+              act=ops.MD_ACT_GEGLU, ln=(il(s1), il(s0), 1e-5))
+    assert _err(out, ref) <= 6e-3 * max(1.0, float(ref.abs().max()))
+    # q|k token-major + V^T transposed
+    w3 = _rand((3 * c, c), 6, dev, c ** -0.5)
+    y3 = F.linear(xn, w3)
+    wl, s1, s0 = engine.fold_layernorm(w3, None, gamma, beta, dev)
+    qk = torch.empty((b, tokens, 2 * c), dtype=F16, device=dev)
+    vt = torch.empty((b, c, tokens), dtype=F16, device=dev)
+    ops.igemm(x16, wl, 3 * c, batch=b, hin=1, win=tokens, hout=1, wout=tokens, c0=c, out=qk, ld_out=2 * c, out_t=vt,
+              n_tr_begin=2 * c, ld_t=tokens, ln=(s1, s0, 1e-5))
+    assert _err(qk, y3[..., :2 * c]) <= 6e-3 * max(1.0, float(y3.abs().max()))
+    assert _err(vt, y3[..., 2 * c:].transpose(1, 2)) <= 6e-3 * max(1.0, float(y3.abs().max()))

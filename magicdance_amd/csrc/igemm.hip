@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   auto compute_tile = [&](int stage) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Ws = As + BM * 128;
+#ifdef MD_IGEMM_DEBUG  // component timing build (tools/igemm_parts.py): -DMD_IGEMM_DEBUG, masks from the environment
     if (g.dbg & 2) return;
     if (g.dbg & 1) {  // LDS operand reads only
 #pragma unroll
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       }
       return;
     }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       h8 af[MF], wf[NF];
@@ -432,7 +434,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt has landed for every wave; every wave is done with stage^1
+#ifdef MD_IGEMM_DEBUG
         if (more && !(g.dbg & 4)) fetch_tile(stage ^ 1);
+#else
+        if (more) fetch_tile(stage ^ 1);
+#endif
       } else {
         if (more) fetch_tile(stage ^ 1);
       }

@@ -1,5 +1,6 @@
 """Component timing of the igemm k-loop (GPU box only): run one big shape with MD_IGEMM_DEBUG masks (set per process)
-and print us per launch + clocks per 64-deep k-tile per CU.  usage: MD_IGEMM_DEBUG=<mask> python tools/igemm_parts.py"""
+and print us per launch + clocks per 64-deep k-tile per CU.  Needs a library built with the debug hooks:
+  MD_EXTRA_FLAGS=-DMD_IGEMM_DEBUG bash magicdance_amd/csrc/build.sh ;  MD_IGEMM_DEBUG=<mask> python tools/igemm_parts.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -172,6 +172,91 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs g) {
   }
 }
 
+
+// Single-launch GroupNorm for SMALL slices (the 32x32 and lower levels of the step are launch-bound: two launches cost
+// ~12 us for a few hundred KB): a block owns `gper` whole groups (cw = gper * cpg channels, a multiple of 8) of one sample
+// and ALL its pixels, so statistics and normalisation need no cross-block exchange: pass 1 reads the slice (fp32 sums,
+// fixed-order reductions -> deterministic), pass 2 re-reads it from L2, normalises, applies SiLU, stores.
+constexpr int GN_SMALL_THREADS = 512, GN_GPER_MAX = 8;
+__global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int gper, int cw8) {
+  __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
+  __shared__ float stat[2 * GN_GPER_MAX];  // mean[gper], rstd[gper]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int v = tid % cw8, pl = tid / cw8, ps = GN_SMALL_THREADS / cw8;  // fixed vector column, pixel lane, pixel stride
+  const bool active = pl < ps;
+  const int c = blockIdx.x * gper * g.cpg + v * 8;
+  const bool first = c < g.c0;
+  const half_t* src = first ? g.x0 + c : g.x1 + (c - g.c0);
+  const long long cs = first ? g.c0 : g.c1;
+  const long long pix0 = (long long)b * g.hw;
+  int lg[8];  // local group of each of this thread's 8 channels
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lg[e] = (v * 8 + e) / g.cpg;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (active) {
+#pragma unroll 4
+    for (int p = pl; p < g.hw; p += ps) {
+      const h8 x = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)x[e];
+        s[e] += f;
+        q[e] += f * f;
+      }
+    }
+  }
+  for (int k = 0; k < gper; ++k) {  // per local group: this thread's share, then wave, then block (fixed order)
+    float a = 0.f, bq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a += lg[e] == k ? s[e] : 0.f;
+      bq += lg[e] == k ? q[e] : 0.f;
+    }
+    a = md::wave_sum(a);
+    bq = md::wave_sum(bq);
+    if (lane == 0) {
+      red[wave][2 * k] = a;
+      red[wave][2 * k + 1] = bq;
+    }
+  }
+  __syncthreads();
+  if (tid < gper) {
+    float sm = 0.f, sq = 0.f;
+    for (int w = 0; w < GN_SMALL_THREADS / 64; ++w) {
+      sm += red[w][2 * tid];
+      sq += red[w][2 * tid + 1];
+    }
+    const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
+    const float mu = sm * inv_n;
+    stat[tid] = mu;
+    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(sq * inv_n - mu * mu, 0.f) + g.eps);
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = stat[GN_GPER_MAX + lg[e]] * g.gamma[c + e];
+    sh[e] = g.beta[c + e] - stat[lg[e]] * sc[e];
+  }
+  half_t* dst = g.out + c;
+#pragma unroll 4
+  for (int p = pl; p < g.hw; p += ps) {
+    const h8 x = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = (float)x[e] * sc[e] + sh[e];
+      if (g.silu) y = md::silu_f(y);
+      o[e] = (half_t)y;
+    }
+    *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
+  }
+}
+
 // stats grid geometry shared by the launcher and the workspace query
 inline void gn_geometry(int batch, int hw, int c, int* ty, int* pix_per_chunk, int* nchunks) {
   const int ch8 = c >> 3;
@@ -280,6 +365,20 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   g.ws = (float*)p->ws;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_NORM, s, 0.0, (double)p->batch * p->hw * c * 2.0 * 3.0);
+  {  // small slices: one launch, a block owns whole groups of one sample (see gn_small)
+    static const long long small_bytes = [] {
+      const char* e = getenv("MD_GN_SMALL_BYTES");
+      return e ? atoll(e) : 96LL << 10;
+    }();
+    int gper = 1;
+    while (gper <= GN_GPER_MAX && ((gper * g.cpg) & 7)) gper <<= 1;
+    if (gper <= GN_GPER_MAX && p->groups % gper == 0 && (long long)p->hw * gper * g.cpg * 2 <= small_bytes &&
+        gper * g.cpg / 8 <= GN_SMALL_THREADS) {
+      hipLaunchKernelGGL(gn_small, dim3(p->groups / gper, g.batch), dim3(GN_SMALL_THREADS), 0, s, g, gper, gper * g.cpg / 8);
+      MD_HIP_CHECK(hipGetLastError());
+      return MD_OK;
+    }
+  }
   const int threads = g.ch8 * g.ty;
   const size_t lds1 = 2 * (size_t)g.ty * c * sizeof(float);
   hipLaunchKernelGGL(gn_stats, dim3(g.nchunks, g.batch), dim3(threads < 64 ? 64 : threads), lds1, s, g);

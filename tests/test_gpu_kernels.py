@@ -208,7 +208,8 @@ def test_attention_spike_rescale(dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 320, 16, 16, None), (1, 64, 8, 8, None), (2, 640, 8, 8, 320), (1, 1920, 4, 4, 1280),
-                                   (1, 320, 64, 64, None)])
+                                   (1, 320, 64, 64, None), (2, 640, 32, 32, None), (2, 960, 32, 32, 640), (1, 128, 32, 32, None),
+                                   (1, 96, 8, 8, None), (1, 2560, 8, 8, 1280), (2, 1280, 16, 16, None), (3, 512, 5, 7, None)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm(dev, shape, silu):
     from magicdance_amd import ops

@@ -96,8 +96,8 @@ def cpu_baseline(model, inp, size, z_hip=None, img_hip=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed frame-batches (each = a full DDIM loop)")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="timed frame-batches (each = a full DDIM loop)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-gpu", type=int, default=1)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--size", type=int, default=64, help="latent side (64 = 512x512)")

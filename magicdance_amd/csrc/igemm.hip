@@ -532,8 +532,25 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
   if (idx >= (long long)g.M * n4) return;
   const int m = (int)(idx / n4);
   const int n = (int)(idx - (long long)m * n4) * 4;
+  // all slab loads of a group of 8 are issued before any is consumed (the loop is latency-, not bandwidth-bound); the
+  // summation ORDER stays z = 0, 1, 2, ... so the result does not depend on the grouping
+  const float* base = g.ws + (long long)m * g.N + n;
+  const long long slab = (long long)g.M * g.N;
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < g.splitk; ++z) s += *reinterpret_cast<const f4*>(g.ws + ((long long)z * g.M + m) * g.N + n);
+  int z = 0;
+  for (; z + 8 <= g.splitk; z += 8) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4*>(base + (z + u) * slab);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; z + 2 <= g.splitk; z += 2) {
+    const f4 v0 = *reinterpret_cast<const f4*>(base + z * slab), v1 = *reinterpret_cast<const f4*>(base + (z + 1) * slab);
+    s += v0;
+    s += v1;
+  }
+  if (z < g.splitk) s += *reinterpret_cast<const f4*>(base + z * slab);
   epi_store4(g, m, m / g.tokens, n, s);
 }
 

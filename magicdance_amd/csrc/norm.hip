@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs g) {
 // Single-launch GroupNorm for SMALL slices (the 32x32 and lower levels of the step are launch-bound: two launches cost
 // ~12 us for a few hundred KB): a block owns `gper` whole groups (cw = gper * cpg channels, a multiple of 8) of one sample
 // and ALL its pixels, so statistics and normalisation need no cross-block exchange: pass 1 reads the slice (fp32 sums,
-// fixed-order reductions -> deterministic), pass 2 re-reads it from L2, normalises, applies SiLU, stores.
-constexpr int GN_SMALL_THREADS = 512, GN_GPER_MAX = 8;
+// fixed-order reductions -> deterministic); the slice stays in registers (measured +0.6 % end to end over re-reading it from
+// L2), is normalised, SiLU-ed and stored.
+constexpr int GN_SMALL_THREADS = 512, GN_GPER_MAX = 8, GN_SMALL_MAXV = 16;
 __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int gper, int cw8) {
   __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
   __shared__ float stat[2 * GN_GPER_MAX];  // mean[gper], rstd[gper]
@@ -193,16 +194,24 @@ __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int
   int lg[8];  // local group of each of this thread's 8 channels
 #pragma unroll
   for (int e = 0; e < 8; ++e) lg[e] = (v * 8 + e) / g.cpg;
+  // the whole slice of this thread (<= GN_SMALL_MAXV vectors, launcher-checked) is loaded up front and stays in registers:
+  // one trip to L2, all loads in flight together
+  h8 x[GN_SMALL_MAXV];
+#pragma unroll
+  for (int i = 0; i < GN_SMALL_MAXV; ++i) {
+    const int p = pl + i * ps;
+    if (active && p < g.hw) x[i] = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+  }
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  if (active) {
-#pragma unroll 4
-    for (int p = pl; p < g.hw; p += ps) {
-      const h8 x = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+#pragma unroll
+  for (int i = 0; i < GN_SMALL_MAXV; ++i) {
+    const int p = pl + i * ps;
+    if (active && p < g.hw) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float f = (float)x[e];
+        const float f = (float)x[i][e];
         s[e] += f;
         q[e] += f * f;
       }
@@ -243,17 +252,19 @@ __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int
     sh[e] = g.beta[c + e] - stat[lg[e]] * sc[e];
   }
   half_t* dst = g.out + c;
-#pragma unroll 4
-  for (int p = pl; p < g.hw; p += ps) {
-    const h8 x = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
-    h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float y = (float)x[e] * sc[e] + sh[e];
-      if (g.silu) y = md::silu_f(y);
-      o[e] = (half_t)y;
+  for (int i = 0; i < GN_SMALL_MAXV; ++i) {
+    const int p = pl + i * ps;
+    if (p < g.hw) {
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = (float)x[i][e] * sc[e] + sh[e];
+        if (g.silu) y = md::silu_f(y);
+        o[e] = (half_t)y;
+      }
+      *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
     }
-    *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
   }
 }
 
@@ -372,9 +383,10 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
     }();
     int gper = 1;
     while (gper <= GN_GPER_MAX && ((gper * g.cpg) & 7)) gper <<= 1;
+    const int cw8 = gper * g.cpg / 8;
     if (gper <= GN_GPER_MAX && p->groups % gper == 0 && (long long)p->hw * gper * g.cpg * 2 <= small_bytes &&
-        gper * g.cpg / 8 <= GN_SMALL_THREADS) {
-      hipLaunchKernelGGL(gn_small, dim3(p->groups / gper, g.batch), dim3(GN_SMALL_THREADS), 0, s, g, gper, gper * g.cpg / 8);
+        cw8 >= 1 && cw8 <= GN_SMALL_THREADS && p->hw <= GN_SMALL_MAXV * (GN_SMALL_THREADS / cw8)) {
+      hipLaunchKernelGGL(gn_small, dim3(p->groups / gper, g.batch), dim3(GN_SMALL_THREADS), 0, s, g, gper, cw8);
       MD_HIP_CHECK(hipGetLastError());
       return MD_OK;
     }

@@ -51,6 +51,7 @@ struct IgemmArgs {
   const float* ln_s1;
   const float* ln_s0;
   float ln_eps, ln_inv_k;
+  int early_w;  // MD_IGEMM_EARLY_W (default 1): first-tile W loads ahead of the row setup
   int dbg;  // MD_IGEMM_DEBUG bit mask (component timing only, results are garbage): 1 no MFMA, 2 no LDS reads + MFMA, 4 no k-loop loads
 };
 
@@ -153,6 +154,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const int lc = tid & 7, lrow = tid >> 3;
   const int gc = lc ^ (lrow & 7);  // row & 7 == lrow & 7 for every row this thread serves
   const int ups = g.ups;           // 0 / 1: source coordinate = virtual coordinate >> ups
+  // 2-stage buffer loader: the W part of the FIRST k-tile depends on nothing computed below, so its LDS-DMA is issued
+  // before the per-row im2col setup (a few hundred VALU): the HBM latency of the layer's cold weights overlaps it
+  [[maybe_unused]] bool skip_w_once = false;
+  if constexpr (LOADER == 2 && STAGES == 2) {
+    if (kt_begin < kt_end && g.early_w) {
+      int tap0 = 0, cc0 = kt_begin * 64;
+      if (g.ksize == 3) {
+        const int cb = kt_begin / 9;
+        tap0 = kt_begin - cb * 9;
+        cc0 = cb * 64;
+      }
+      const unsigned ksoff0 = (unsigned)(tap0 * g.cin + cc0) * 2u;
+      const __amdgpu_buffer_rsrc_t rs_w0 =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), 0, g.N * g.K * 2, 0x00020000);
+      char* Ws0 = smem + BM * 128;
+#pragma unroll
+      for (int j = 0; j < (BN + 31) / 32; ++j) {
+        if ((BN % 32) != 0 && j == (BN + 31) / 32 - 1 && wave >= 2) break;
+        const unsigned wo = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u + (unsigned)gc * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0, (__attribute__((address_space(3))) void*)(Ws0 + (32 * j + 8 * wave) * 128),
+                                                 16, wo, ksoff0, 0, 0);
+      }
+      skip_w_once = true;
+    }
+  }
   const int vh = g.hin << ups, vw = g.win << ups;
   int a_y[AJ], a_x[AJ], a_pix[AJ], a_mask[AJ];
 #pragma unroll
@@ -261,11 +287,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
                                                    16, voff[j], soff, 0, 0);
       }
       const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
+      if (skip_w_once) {
+        skip_w_once = false;  // the first tile's W part is already in flight (issued ahead of the row setup)
+      } else {
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        if (W_TAIL && j == WJ - 1 && wave >= 2) break;  // wave-uniform: rows 32 j + 8 wave .. + 7 lie beyond BN
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
-                                                 16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
+        for (int j = 0; j < WJ; ++j) {
+          if (W_TAIL && j == WJ - 1 && wave >= 2) break;  // wave-uniform: rows 32 j + 8 wave .. + 7 lie beyond BN
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
+                                                   16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
+        }
       }
       ++kt_i;
       if (g.ksize == 3) {
@@ -750,6 +780,11 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.ln_s0 = p->ln_s0;
   g.ln_eps = p->ln_eps;
   g.ln_inv_k = 1.0f / (float)g.K;
+  static const int early_w = [] {
+    const char* e = getenv("MD_IGEMM_EARLY_W");
+    return e ? atoi(e) : 1;
+  }();
+  g.early_w = early_w;
   static const int dbg = [] {
     const char* e = getenv("MD_IGEMM_DEBUG");
     return e ? atoi(e) : 0;

@@ -109,7 +109,7 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 // the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
 //   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
 //   MFMAs on the landed stage.  Tiles past the end are fetched from the zero page so the outstanding count is constant.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
   constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   constexpr bool W_TAIL = (BN % 32) != 0;
   static_assert(!W_TAIL || LOADER == 2, "ragged BN is implemented for the buffer loader only");
   static_assert(BM % 32 == 0 && BN % 16 == 0, "tile shape");
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  // KT = 64-deep k-tiles per pipeline stage.  KT = 2 (small tiles, 2-stage buffer loader): one vmcnt(0)+barrier round trip
+  // fetches two k-tiles -- the k-loop of a small GEMM on cold weights is one HBM round trip per iteration, so twice the
+  // bytes per trip halves its length.  LDS addressing is by SLOT = stage * KT + sub-tile.
+  constexpr int STAGE_BYTES = (BM + BN) * 128;   // bytes of ONE k-tile slot
+  static_assert(KT == 1 || (LOADER == 2 && STAGES == 2), "multi-tile stages exist for the 2-stage buffer loader");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -448,7 +452,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the zero-page tail fetches before LDS is released
   } else {
     if constexpr (GLDS) {
-      if (kt_begin < kt_end) fetch_tile(0);
+      if (kt_begin < kt_end) {
+#pragma unroll
+        for (int u = 0; u < KT; ++u) fetch_tile(u, kt_begin + u < kt_end);
+      }
     } else {
       if (kt_begin < kt_end) {
         fetch_tile(0);
@@ -456,23 +463,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       }
       __syncthreads();
     }
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int stage = (kt - kt_begin) & 1;
-      const bool more = kt + 1 < kt_end;
+    for (int kt = kt_begin; kt < kt_end; kt += KT) {
+      const int stage = ((kt - kt_begin) / KT) & 1;
+      const bool more = kt + KT < kt_end;
       if constexpr (GLDS) {
         // explicit drain of this wave's LDS-DMA: the compiler's own wait before a barrier is not reliable for
         // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile kt has landed for every wave; every wave is done with stage^1
+        __syncthreads();  // tiles kt.. have landed for every wave; every wave is done with stage^1
 #ifdef MD_IGEMM_DEBUG
-        if (more && !(g.dbg & 4)) fetch_tile(stage ^ 1);
+        if (more && !(g.dbg & 4))
 #else
-        if (more) fetch_tile(stage ^ 1);
+        if (more)
 #endif
+        {
+#pragma unroll
+          for (int u = 0; u < KT; ++u) fetch_tile((stage ^ 1) * KT + u, kt + KT + u < kt_end);
+        }
       } else {
         if (more) fetch_tile(stage ^ 1);
       }
-      compute_tile(stage);
+#pragma unroll
+      for (int u = 0; u < KT; ++u)
+        if (KT == 1 || kt + u < kt_end) compute_tile(stage * KT + u);
       if constexpr (!GLDS) {
         if (more) store_tile(stage ^ 1);
         __syncthreads();
@@ -587,14 +600,17 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 // families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
 //           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
-const float kTileEff[8] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f};
-const int kTileBM[8] = {128, 128, 64, 64, 128, 128, 64, 64}, kTileBN[8] = {128, 64, 128, 64, 80, 160, 160, 80};
+const float kTileEff[12] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f};
+const int kTileBM[12] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64};
+const int kTileBN[12] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160};
 constexpr int kNumFamilies = 6;
 constexpr int kNumCfgs = 4 * kNumFamilies;
 // configs 24..27: SD-shaped tiles of the buffer loader (2 stages) -- 128x80, 128x160, 64x160, 64x80.  Every channel count of
 // SD-1.5 is a multiple of 80 (320 = 4 x 80), so these cover N exactly where the 64 / 128-wide tiles waste up to 17 %, and e.g.
 // M = 8192, N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
-constexpr int kFirstSdCfg = 24, kNumAllCfgs = 28;
+// configs 28..31: two k-tiles per stage (KT = 2) for 64x64, 64x80, 128x80, 64x160 -- half the HBM round trips in the k-loop
+// of the small cold-weight GEMMs of a 1-frame step.
+constexpr int kFirstSdCfg = 24, kNumAllCfgs = 32;
 struct TileCfg {
   int bm, bn;
   float eff;
@@ -603,31 +619,34 @@ inline TileCfg cfg_of(int c) {
   const int t = c >= kFirstSdCfg ? 4 + (c - kFirstSdCfg) : (c & 3);
   return TileCfg{kTileBM[t], kTileBN[t], kTileEff[t]};
 }
+// tiles whose per-wave fragment count along N is odd cannot host the GEGLU pairing
+inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28; }
+inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || c >= kFirstSdCfg; }
 // default loader family: MD_IGEMM_LOADER = 0..4
 int g_default_loader = [] {
   const char* e = getenv("MD_IGEMM_LOADER");
   return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
 }();
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false>
+template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 128;
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN>),
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
 
 // the 2-stage buffer-loader tiles exist with and without the folded LayerNorm
-template <int BM, int BN, int WMv, int WNv>
+template <int BM, int BN, int WMv, int WNv, int KT = 1>
 int launch_buf2(const IgemmArgs& g, hipStream_t s) {
-  return g.ln_s1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, true>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false>(g, s);
+  return g.ln_s1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, true, KT>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT>(g, s);
 }
 
 void fast_div_magic(unsigned d, unsigned* mul, unsigned* sh) {
@@ -681,8 +700,8 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
       if (t->m == M && t->n == N && t->k == K && t->ksize == p->ksize && t->stride == p->stride && t->ups == p->ups) {
         const bool ok_split = t->split == 1 || (p->act != MD_ACT_GEGLU && (long long)t->split * M * N * 4 <= ws_bytes);
         const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
-        const bool ok_act = t->cfg < kFirstSdCfg || p->act != MD_ACT_GEGLU;
-        const bool ok_ln = !p->ln_s1 || (t->split == 1 && t->cfg >= 12);
+        const bool ok_act = cfg_geglu_ok(t->cfg) || p->act != MD_ACT_GEGLU;
+        const bool ok_ln = !p->ln_s1 || (t->split == 1 && cfg_ln_ok(t->cfg));
         if (ok_split && ok_buf && ok_act && ok_ln) {
           *cfg_out = t->cfg;
           *split_out = t->split;
@@ -795,8 +814,8 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
-  if (cfg >= kFirstSdCfg && (cfg >= kNumAllCfgs || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
-  if (p->ln_s1 && (split > 1 || !((cfg >= 12 && cfg < 16) || cfg >= kFirstSdCfg))) return MD_ERR_UNSUPPORTED;
+  if (cfg >= kNumAllCfgs || (p->act == MD_ACT_GEGLU && !cfg_geglu_ok(cfg))) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
+  if (p->ln_s1 && (split > 1 || !cfg_ln_ok(cfg))) return MD_ERR_UNSUPPORTED;
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
@@ -823,6 +842,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
     case 25: rc = launch_buf2<128, 160, 2, 2>(g, s); break;
     case 26: rc = launch_buf2<64, 160, 2, 2>(g, s); break;
     case 27: rc = launch_buf2<64, 80, 4, 1>(g, s); break;
+    case 28: rc = launch_buf2<64, 64, 2, 2, 2>(g, s); break;
+    case 29: rc = launch_buf2<64, 80, 4, 1, 2>(g, s); break;
+    case 30: rc = launch_buf2<128, 80, 4, 1, 2>(g, s); break;
+    case 31: rc = launch_buf2<64, 160, 2, 2, 2>(g, s); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
     case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
     case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;

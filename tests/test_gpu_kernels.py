@@ -59,7 +59,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31])
 def test_igemm_conv(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cins, h, w, cout, k, stride, ups = case
@@ -344,7 +344,7 @@ def test_gather_rows(dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 320, 960), (1, 64, 1280, 1280), (2, 1000, 640, 640), (1, 77, 64, 128)])
-@pytest.mark.parametrize("cfg", [-1, 12, 15, 24, 26, 27])
+@pytest.mark.parametrize("cfg", [-1, 12, 15, 24, 26, 27, 28, 29, 31])
 def test_igemm_folded_layernorm(dev, shape, cfg):
     """md_igemm ln_*: LayerNorm(x) W^T + b with gamma folded into W and the row statistics accumulated in the k-loop,
     against F.layer_norm + F.linear (attention.py norm1/2/3 -> to_q|k|v / to_q / GEGLU proj)."""

@@ -600,17 +600,17 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 // families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
 //           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
-const float kTileEff[12] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f};
-const int kTileBM[12] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64};
-const int kTileBN[12] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160};
+const float kTileEff[14] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f, 0.70f, 0.60f};
+const int kTileBM[14] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64, 64, 64};
+const int kTileBN[14] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160, 64, 80};
 constexpr int kNumFamilies = 6;
 constexpr int kNumCfgs = 4 * kNumFamilies;
 // configs 24..27: SD-shaped tiles of the buffer loader (2 stages) -- 128x80, 128x160, 64x160, 64x80.  Every channel count of
 // SD-1.5 is a multiple of 80 (320 = 4 x 80), so these cover N exactly where the 64 / 128-wide tiles waste up to 17 %, and e.g.
 // M = 8192, N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
 // configs 28..31: two k-tiles per stage (KT = 2) for 64x64, 64x80, 128x80, 64x160 -- half the HBM round trips in the k-loop
-// of the small cold-weight GEMMs of a 1-frame step.
-constexpr int kFirstSdCfg = 24, kNumAllCfgs = 32;
+// of the small cold-weight GEMMs of a 1-frame step; 32, 33: four k-tiles per stage for 64x64, 64x80 (128 / 147 KB of LDS).
+constexpr int kFirstSdCfg = 24, kNumAllCfgs = 34;
 struct TileCfg {
   int bm, bn;
   float eff;
@@ -620,7 +620,7 @@ inline TileCfg cfg_of(int c) {
   return TileCfg{kTileBM[t], kTileBN[t], kTileEff[t]};
 }
 // tiles whose per-wave fragment count along N is odd cannot host the GEGLU pairing
-inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28; }
+inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28 || c == 32; }
 inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || c >= kFirstSdCfg; }
 // default loader family: MD_IGEMM_LOADER = 0..4
 int g_default_loader = [] {
@@ -846,6 +846,8 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
     case 29: rc = launch_buf2<64, 80, 4, 1, 2>(g, s); break;
     case 30: rc = launch_buf2<128, 80, 4, 1, 2>(g, s); break;
     case 31: rc = launch_buf2<64, 160, 2, 2, 2>(g, s); break;
+    case 32: rc = launch_buf2<64, 64, 2, 2, 4>(g, s); break;
+    case 33: rc = launch_buf2<64, 80, 4, 1, 4>(g, s); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
     case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
     case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;

@@ -59,7 +59,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33])
 def test_igemm_conv(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cins, h, w, cout, k, stride, ups = case

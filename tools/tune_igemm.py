@@ -70,6 +70,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
         cfgs += [24, 25, 26, 27]   # SD-shaped tiles (BN = 80 / 160)
     if buf_ok and M <= 16384:
         cfgs += [28] + ([29, 30, 31] if (N % 80 == 0 and act != 2) else [])   # two k-tiles per stage
+        if M <= 4096:
+            cfgs += [32] + ([33] if (N % 80 == 0 and act != 2) else [])       # four
     if buf_ok and os.environ.get("TUNE_DEEP"):
         cfgs += list(range(16, 24))  # counted-vmcnt 3..6-stage pipelines (exploration only, see igemm.hip)
     nk = (K + 63) // 64

@@ -174,3 +174,19 @@ def test_variants_match_reference_golden(dev, name):
                             img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
     assert _rel(z.cpu().numpy(), g["z"], f"{name} z({int(g['steps'])} steps) vs golden") <= TOL_Z
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], f"{name} pred_x0 trajectory vs golden") <= TOL_Z
+
+
+def test_repeated_sampling_is_bit_identical(dev):
+    """The reference-KV table pass runs on its own stream ahead of the captured step graphs (own arena / workspaces): any
+    missing dependency between the two would show up as run-to-run differences.  (tools/repeat_check.py: 30 full-size runs.)"""
+    g = H.load_golden("small_b1")
+    model = _model(g, dev)
+    inp = H.case_inputs(g)
+    c, uc, x_T = _to_dev(inp["c"], dev), _to_dev(inp["uc"], dev), inp["x_T"].to(dev)
+    outs = []
+    for _ in range(4):
+        z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=20, eta=0.0, unconditional_guidance_scale=7,
+                                unconditional_conditioning=uc, inpaint=None, x_T=x_T)
+        outs.append(z.clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])

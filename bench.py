@@ -7,8 +7,9 @@ update per step) and the first-stage (VAE) decode of the frames, latents in -> d
 HBM before the timed region; nothing is cached across batches (the table is recomputed for every batch).
 N=1 default workload = BASELINE.json configs[1]: single 512x512 frame, 50-step DDIM, full Appearance+Pose ControlNet,
 fp16, random-init (seeded synthetic) SD-1.5-geometry weights.  N>1: one process per GPU (torch.distributed over RCCL),
-frames sharded across ranks (weak scaling: `--frames-per-gpu` each), the reference-image KV table computed in row
-blocks (one block of timesteps per rank) and exchanged with RCCL broadcasts, final latents all-gathered.
+frames sharded across ranks (weak scaling: `--frames-per-gpu` each), the reference-image KV table computed in equal row
+blocks (one block of timesteps per rank) and exchanged with one RCCL all-gather per table segment, decoded frames
+all-gathered.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (igemm = the dominant kernel family, HIP-event timed per
 launch on the launch stream) and "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample).

@@ -255,7 +255,9 @@ class FusedStepRunner:
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
 
-    def prepare(self, c, x_T, sampler, scale, table_mode=False):
+    def prepare(self, c, x_T, sampler, scale, table_mode=False, table_rows=None):
+        """``table_rows`` >= S: rows allocated per table segment (frame sharding pads S to a multiple of the world size so
+        that every rank owns an equal block and the exchange is one all-gather per segment)."""
         model, dev = self.model, self.model.device
         app, pose_e, unet = model.engines()
         b, cch, hh, ww = x_T.shape
@@ -279,10 +281,11 @@ class FusedStepRunner:
         self.kv_unet = unet.context_kv(self._ctx_unet)
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
-        key = (b, cch, hh, ww, S, ref.shape[0], tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
+        rows = S if table_rows is None else max(int(table_rows), S)
+        key = (b, cch, hh, ww, S, rows, ref.shape[0], tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
                self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
         if key != self.key:
-            self._allocate(key, b, cch, hh, ww, S, ref.shape[0], table_mode)
+            self._allocate(key, b, cch, hh, ww, S, ref.shape[0], table_mode, rows)
         self.ref.copy_(ref)
         self.x.copy_(x_T)
         hf = pose_e.hint_features(hint)
@@ -304,12 +307,13 @@ class FusedStepRunner:
             self.graph.destroy()
             self.graph = None
 
-    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
+    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode, rows=None):
         from .nets import bank_shapes
         dev = self.model.device
         self._drop_graph()
         self.key, self.table_mode = key, table_mode
         self.b, self.cch, self.hw, self.S = b, cch, hh * ww, S
+        R = self.table_rows = S if rows is None else rows
         self.x = torch.empty((b, cch, hh, ww), dtype=F32, device=dev)
         self.pred_x0 = torch.empty_like(self.x)
         self.ref = torch.empty((bref, cch, hh, ww), dtype=F32, device=dev)
@@ -327,9 +331,9 @@ class FusedStepRunner:
             for n, c in bank_shapes(app.cfg, (hh, ww)):
                 ldv = (n + 7) & ~7
                 lk, lv = bref * n * c, bref * c * ldv
-                self.bank_geo.append((toff, toff + S * lk, coff, coff + lk, n, c, ldv))
-                segs += [(toff // 8, lk // 8, coff // 8), ((toff + S * lk) // 8, lv // 8, (coff + lk) // 8)]
-                toff += S * (lk + lv)
+                self.bank_geo.append((toff, toff + R * lk, coff, coff + lk, n, c, ldv))
+                segs += [(toff // 8, lk // 8, coff // 8), ((toff + R * lk) // 8, lv // 8, (coff + lk) // 8)]
+                toff += R * (lk + lv)
                 coff += lk + lv
             self.bank_table = torch.zeros((toff,), dtype=F16, device=dev)   # zeros: the V^T pad columns stay zero
             self.bank_cur = torch.zeros((coff,), dtype=F16, device=dev)

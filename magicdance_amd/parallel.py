@@ -7,8 +7,8 @@ block of frames and runs them as one batch.  The only shared quantity is the app
 depends on (reference latent, t, ctx) only, i.e. on the DDIM step but not on the frame.  The S banks are therefore
 computed once per sequence: rank r runs the appearance net for a contiguous block of S/world steps (batched over those
 timesteps) and applies the UNet's to_k / to_v to them -- the "reference-image KV" of the north star, 46 MB fp16 per
-step at 512x512 -- and the blocks are exchanged with RCCL broadcasts (point-to-point xGMI links: each broadcast is a
-direct root->peers fan-out of one contiguous table slab).  After that the 50-step loop has no collective at all:
+step at 512x512 -- and the equal row blocks are exchanged with one RCCL all-gather per table segment (point-to-point xGMI
+links: every link carries a different block at the same time).  After that the 50-step loop has no collective at all:
 every rank replays its captured step graph (pose ControlNet + UNet cond/uncond + CFG/DDIM update) reading table row
 ``step``.  Final latents are all-gathered (the decoded-frame gather of the north star, at the latent seam of this
 round's scope).
@@ -30,25 +30,30 @@ class FrameShardedSampler:
         uc = {"c_concat": [pose], "c_crossattn": [rep(ctx)], "wonoise": True, "overlap_sampling": False}
         return c, uc
 
+    def table_rows(self, S):
+        """Rows per table segment: S padded to a multiple of the world size (equal blocks -> one all-gather per segment)."""
+        return -(-S // self.world) * self.world
+
     def row_block(self, S, rank):
-        """DDIM rows [r0, r1) whose reference-KV this rank computes (contiguous, as even as S % world allows)."""
-        q, r = divmod(S, self.world)
-        r0 = rank * q + min(rank, r)
-        return r0, r0 + q + (1 if rank < r else 0)
+        """DDIM rows [r0, r1) whose reference-KV this rank computes: the valid part of its equal block of the padded table."""
+        q = self.table_rows(S) // self.world
+        return min(S, rank * q), min(S, (rank + 1) * q)
 
     def _fill_table(self, st):
         """Reference-KV table of the whole schedule: every rank runs the appearance net (batched over its block of
-        timesteps) for S/world rows and the blocks are exchanged with RCCL broadcasts -- each one a direct root->peers
-        fan-out over the point-to-point xGMI links of (row block x one bank entry's K or V^T), 32 pieces per rank."""
+        timesteps) for ~S/world rows, then ONE RCCL all-gather per table segment (K or V^T of a bank entry, 32 segments)
+        exchanges the equal row blocks -- every xGMI link carries a different block at the same time, instead of world x 32
+        root->peers broadcasts one after the other."""
         r0, r1 = self.row_block(st.S, self.rank)
-        st.compute_bank_rows(range(r0, r1))
+        if r1 > r0:
+            st.compute_bank_rows(range(r0, r1))
         if self.world > 1:
             import torch.distributed as dist
-            for src in range(self.world):
-                s0, s1 = self.row_block(st.S, src)
-                if s1 > s0:
-                    for slab in st.table_slabs(s0, s1):
-                        dist.broadcast(slab, src=src, group=self.group)
+            q = st.table_rows // self.world
+            per_rank = [st.table_slabs(src * q, (src + 1) * q) for src in range(self.world)]   # [rank][segment] views
+            for seg in range(len(per_rank[0])):
+                outs = [per_rank[src][seg] for src in range(self.world)]
+                dist.all_gather(outs, outs[self.rank].clone(), group=self.group)
 
     @torch.no_grad()
     def sample(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, gather=True, decode=False):
@@ -71,7 +76,7 @@ class FrameShardedSampler:
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            st.prepare(c, x_T, sampler, scale, table_mode=True)
+            st.prepare(c, x_T, sampler, scale, table_mode=True, table_rows=self.table_rows(ddim_steps))
             S = st.S
             self._fill_table(st)
             for _ in range(S):
@@ -110,7 +115,8 @@ class FrameShardedSampler:
                 b = pose.shape[0]
                 c, _ = self._cond(pose, ctx, ref)
                 old_key = st.key
-                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True)
+                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True,
+                           table_rows=self.table_rows(ddim_steps))
                 if not have_table or st.key != old_key:   # (re)allocated buffers: the table must be filled for this geometry
                     self._fill_table(st)
                     have_table = True

@@ -80,6 +80,22 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
     return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2).numpy()
 
 
+def adapt_clip_keys(state_dict, model_keys, prefix="cond_stage_model.transformer."):
+    """Checkpoints written with transformers 4.x name the text tower ``<prefix>text_model.*`` (and carry a ``position_ids``
+    buffer); transformers 5 drops that level.  Rename towards whatever the instantiated module uses."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith(prefix) and k not in model_keys:
+            rest = k[len(prefix):]
+            alt = prefix + (rest[len("text_model."):] if rest.startswith("text_model.") else "text_model." + rest)
+            if alt in model_keys:
+                k = alt
+            elif rest.endswith("position_ids"):
+                continue
+        out[k] = v
+    return out
+
+
 class _Unavailable(nn.Module):
     """Placeholder for VAE / CLIP when their implementation is not importable in this image."""
 
@@ -188,6 +204,8 @@ class ControlLDMReferenceOnlyPose(nn.Module):
                      if m is None or isinstance(m, _Unavailable))
         if drop:
             state_dict = {k: v for k, v in state_dict.items() if not k.startswith(drop)}
+        if not any(p.startswith("cond_stage_model") for p in drop):
+            state_dict = adapt_clip_keys(state_dict, set(self.state_dict().keys()))
         self._fused = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 

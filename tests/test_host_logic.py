@@ -149,3 +149,36 @@ def test_variant_host_logic_matches_reference_golden(monkeypatch, name):
                             unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"] if stage1 else inp["uc_balance"],
                             inpaint=None, x_T=inp["x_T"])
     assert _rel(z.numpy(), g["z"]) <= 1e-2
+
+
+def test_clip_embedder_wrapper_behaviour():
+    """magicdance_amd.clip.FrozenCLIPEmbedder (stock transformers): key layout and the three ``layer`` modes.
+    The tokenizer vocabulary is not in this image, so a stand-in tokenizer feeds fixed ids to a small random CLIP text model."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from magicdance_amd.clip import FrozenCLIPEmbedder
+    emb = FrozenCLIPEmbedder.__new__(FrozenCLIPEmbedder)
+    torch.nn.Module.__init__(emb)
+    cfg = CLIPTextConfig(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                         max_position_embeddings=77, eos_token_id=99, bos_token_id=98, pad_token_id=99)
+    emb.transformer = CLIPTextModel(cfg)
+    ids = torch.full((2, 77), 99, dtype=torch.long)
+    ids[:, 0] = 98
+    emb.tokenizer = lambda text, **kw: {"input_ids": ids[:len(text)]}
+    emb.device, emb.max_length, emb.layer, emb.layer_idx = "cpu", 77, "last", None
+    emb.freeze()
+    keys = set("cond_stage_model." + k for k in emb.state_dict())
+    assert all(k.startswith("cond_stage_model.transformer.") for k in keys)
+    # a checkpoint written with transformers 4.x (extra ``text_model.`` level + position_ids buffer) maps onto this module
+    from magicdance_amd.cldm import adapt_clip_keys
+    strip = "cond_stage_model.transformer."
+    old = {strip + "text_model." + k[len(strip):]: 0 for k in keys if not k[len(strip):].startswith("text_model.")}
+    old.update({k: 0 for k in keys if k[len(strip):].startswith("text_model.")})
+    old[strip + "text_model.embeddings.position_ids"] = 0
+    assert set(adapt_clip_keys(old, keys)) == keys
+    assert not any(p.requires_grad for p in emb.parameters())
+    z = emb.encode(["", "a person dancing"])
+    assert tuple(z.shape) == (2, 77, 64)
+    emb.layer = "pooled"
+    assert tuple(emb(["x"]).shape) == (1, 1, 64)
+    emb.layer, emb.layer_idx = "hidden", -2
+    assert tuple(emb(["x"]).shape) == (1, 77, 64)

@@ -231,8 +231,8 @@ class FusedStepRunner:
                of every bank entry are applied there too.  ``bank_table`` holds, per bank entry, K [S, bref, n, c] and
                V^T [S, bref, c, ldv] (46 MB fp16 per step at 512x512, 2.3 GB for 50 steps); the step graph gathers row
                ``counter`` into ``bank_cur`` with one md_gather_rows launch and skips the appearance net and the bank
-               projections.  The same table serves multi-GPU frame sharding (row blocks computed per rank and exchanged
-               with RCCL broadcasts, magicdance_amd/parallel.py) and multi-frame sequences sharing one reference image.
+               projections.  The same table serves multi-GPU frame sharding (equal row blocks computed per rank and exchanged
+               with RCCL all-gathers, magicdance_amd/parallel.py) and multi-frame sequences sharing one reference image.
     """
 
     def __init__(self, model):

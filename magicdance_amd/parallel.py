@@ -95,7 +95,7 @@ class FrameShardedSampler:
     def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0, decode=False):
         """A whole pose sequence sharing one reference image (the entry points' use case, test_any_image_pose.py:201-262:
         same ref latent, same text, same x_T for every frame).  With ``wonoise`` the appearance bank depends on the DDIM
-        step only, so the S banks are computed ONCE per sequence (round-robin over ranks + RCCL broadcast when world > 1)
+        step only, so the S banks are computed ONCE per sequence (equal row blocks per rank + RCCL all-gathers when world > 1)
         and every batch of ``frames_per_batch`` frames replays the captured step graph in table mode.
         pose_frames [F,3,8h,8w] = this rank's frames; x_T [1,4,h,w].  Returns this rank's latents [F,4,h,w]."""
         model = self.model

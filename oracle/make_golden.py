@@ -87,10 +87,66 @@ def run_case(name):
     print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
 
 
+TRAJ_CASES = {
+    # BASELINE.json configs at the full SD-1.5 geometry, latent 64x64 (512x512): (latent side, frames, ddim steps, probe t)
+    "c0_b1_s20": (64, 1, 20, 951),    # configs[0]: single frame, 20-step DDIM
+    "c1_b1_s50": (64, 1, 50, 981),    # configs[1]: single frame, 50-step DDIM (the headline)
+    "c2_b8_s2": (64, 8, 2, 981),      # configs[2] geometry: 8 pose frames as one batch (reference recipe train_tiktok.py:408-444)
+}
+
+
+def run_traj_case(name):
+    """Full-size parity fixtures: eps_c / eps_u of one apply_model pair and the WHOLE x_t trajectory of sample_log
+    (log_every_t=1 -> intermediates['x_inter'] holds x_T and every x_{t-1}); bank / pose tensors as head slices + statistics."""
+    side, frames, steps, t_probe = TRAJ_CASES[name]
+    torch.manual_seed(0)
+    t0 = time.time()
+    m = ref_shim.build_reference_model({}, image_size=side)
+    sd = {}
+    for pre, mod in [(PREFIXES["unet"], m.model.diffusion_model), (PREFIXES["app"], m.appearance_control_model),
+                     (PREFIXES["pose"], m.pose_control_model)]:
+        sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
+    m.load_state_dict(sd, strict=False)
+    del sd
+    inp = synthetic.synth_inputs((side, side), frames=frames, seed=0)
+    rep = lambda x: x.repeat(frames, 1, 1, 1) if x.dim() == 4 else x.repeat(frames, 1, 1)
+    ref, ctx, x_T, pose = rep(inp["ref"]), rep(inp["ctx"]), rep(inp["x_T"]), inp["pose"]
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
+    out = dict(geo_model_channels=320, geo_num_heads=8, side=side, frames=frames, t_probe=t_probe, steps=steps, seed=0,
+               x_T=inp["x_T"].numpy(), ref=inp["ref"].numpy(), ctx_sum=summarize(ctx), pose_sum=summarize(pose))
+    t = torch.full((frames,), t_probe, dtype=torch.long)
+    with torch.no_grad():
+        if frames == 1:
+            bank = []
+            m.appearance_control_model(x=ref, hint=None, timesteps=t, context=ctx, attention_bank=bank,
+                                       attention_mode="write", uc=False)
+            for i, b in enumerate(bank):
+                out[f"bank{i}_head"], out[f"bank{i}_sum"] = head_slice(b[0]), summarize(b[0])
+            del bank
+            pr = m.pose_control_model(x=x_T, hint=pose, timesteps=t, context=ctx)
+            for i, p in enumerate(pr):
+                out[f"pose{i}_head"], out[f"pose{i}_sum"] = head_slice(p), summarize(p)
+            del pr
+        out["eps_c"] = m.apply_model(x_T, t, c, ref).numpy()
+        out["eps_u"] = m.apply_model(x_T, t, c, None, uc=True).numpy()
+        print(f"[golden] {name}: probes done {time.time() - t0:.0f}s", flush=True)
+        z, inter = m.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=steps, eta=0.0,
+                                unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=x_T,
+                                log_every_t=1)
+        out["z"] = z.numpy()
+        out["x_traj"] = torch.stack(inter["x_inter"]).numpy()        # [steps + 1, frames, 4, side, side]
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s", flush=True)
+
+
 VARIANT_CASES = {
     # name: (variant, net overrides, latent side, t probe, ddim steps) -- other branches of the same config surface (SURVEY 8f-4)
     "small_b1_balance": ("balance", dict(model_channels=64, num_heads=2), 16, 501, 4),
     "small_b1_stage1": ("stage1", dict(model_channels=64, num_heads=2), 16, 501, 4),
+    "small_b1_noisy": ("noisy", dict(model_channels=64, num_heads=2), 16, 501, 4),
+    "small_b16_overlap": ("overlap", dict(model_channels=64, num_heads=2), 8, 501, 2),
 }
 
 
@@ -110,27 +166,57 @@ def run_variant_case(name):
     for pre, mod in mods:
         sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
     m.load_state_dict(sd, strict=False)
-    inp = synthetic.synth_inputs((side, side), frames=1, seed=0)
+    frames = 16 if variant == "overlap" else 1
+    inp = synthetic.synth_inputs((side, side), frames=frames, seed=0)
     ctx_u = synthetic.synth_inputs((side, side), frames=1, seed=7)["ctx"]
-    ref, ctx, x_T, pose = inp["ref"], inp["ctx"], inp["x_T"], inp["pose"]
-    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
-    uc = {"c_concat": [pose], "c_crossattn": [ctx_u if variant == "balance" else ctx], "wonoise": True, "overlap_sampling": False}
+    rep = lambda x: x.repeat(frames, 1, 1, 1) if x.dim() == 4 else x.repeat(frames, 1, 1)
+    ref, ctx, x_T, pose = rep(inp["ref"]), rep(inp["ctx"]), rep(inp["x_T"]), inp["pose"]
+    if variant == "overlap":   # per-frame noise, as the reference's multi-frame recipe draws it (train_tiktok.py:431-432)
+        x_T = torch.randn(frames, 4, side, side, generator=torch.Generator().manual_seed(55))
+    wonoise = variant != "noisy"
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": wonoise,
+         "overlap_sampling": variant == "overlap"}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx_u if variant == "balance" else ctx], "wonoise": wonoise,
+          "overlap_sampling": variant == "overlap"}
     if variant == "balance":
         uc["image_control"] = [ref]
-    out = dict(geo_model_channels=geo["model_channels"], geo_num_heads=geo["num_heads"], side=side, frames=1, t_probe=t_probe,
-               steps=steps, seed=0, x_T=x_T.numpy(), ref=ref.numpy(), ctx_sum=summarize(ctx), pose_sum=summarize(pose),
+    noises = []
+    if variant == "noisy":
+        # wonoise=False (ddim.py:529-535): q_sample draws randn_like per step (ddpm.py:356-359).  The harness draws the SAME
+        # call's noise itself and hands it in through q_sample's own ``noise`` argument, recording it for the fixture.
+        orig_q = m.q_sample
+
+        def rec_q(x_start, t, noise=None):
+            n = torch.randn_like(x_start) if noise is None else noise
+            noises.append(n.clone())
+            return orig_q(x_start, t, noise=n)
+        m.q_sample = rec_q
+    if variant == "overlap":
+        # ddim.py:569-594 moves tensors with .cpu()/.cuda(); on the CPU shim .cuda() is made the identity.  The window
+        # offset comes from python's ``random`` (ddim.py:575): seeded here, the test seeds it identically.
+        import random
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        random.seed(1234)
+    out = dict(geo_model_channels=geo["model_channels"], geo_num_heads=geo["num_heads"], side=side, frames=frames, t_probe=t_probe,
+               steps=steps, seed=0, x_T=(x_T if variant == "overlap" else inp["x_T"]).numpy(), ref=inp["ref"].numpy(),
+               ctx_sum=summarize(inp["ctx"]), pose_sum=summarize(pose),
                state_keys=np.array("\n".join(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()
                                              if k.startswith(("model.", "control_model.", "appearance_", "pose_")))))
-    t = torch.full((1,), t_probe, dtype=torch.long)
+    t = torch.full((frames,), t_probe, dtype=torch.long)
     with torch.no_grad():
-        out["eps_c"] = m.apply_model(x_T, t, c, ref).numpy()
-        out["eps_u"] = m.apply_model(x_T, t, c, None, uc=True).numpy()
+        if variant not in ("noisy", "overlap"):
+            out["eps_c"] = m.apply_model(x_T, t, c, ref).numpy()
+            out["eps_u"] = m.apply_model(x_T, t, c, None, uc=True).numpy()
         traj = []
-        z, _ = m.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
+        z, _ = m.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
                             unconditional_conditioning=uc, inpaint=None, x_T=x_T,
                             img_callback=lambda pred_x0, i: traj.append(pred_x0.clone()))
         out["z"] = z.numpy()
         out["pred_x0_traj"] = torch.stack(traj).numpy()
+    if noises:
+        out["q_noises"] = torch.stack(noises).numpy()
+    if variant == "overlap":
+        out["random_seed"] = 1234
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
@@ -174,4 +260,11 @@ def run_vae_case(name):
 
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES) + list(VARIANT_CASES) + list(VAE_CASES)):
-        run_vae_case(n) if n in VAE_CASES else (run_variant_case(n) if n in VARIANT_CASES else run_case(n))
+        if n in VAE_CASES:
+            run_vae_case(n)
+        elif n in VARIANT_CASES:
+            run_variant_case(n)
+        elif n in TRAJ_CASES:
+            run_traj_case(n)
+        else:
+            run_case(n)

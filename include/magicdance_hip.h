@@ -87,6 +87,14 @@ typedef struct {
   int32_t asym_pad;        /* 1: no padding on the top/left side, taps of output (oy, ox) start at source (stride*oy,
                             * stride*ox) and run off the bottom/right edge into zeros: the VAE encoder's Downsample,
                             * F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (ldm/modules/diffusionmodules/model.py:80-84) */
+  /* Two-term fp16 residual stream (ABI v2).  The reference keeps `x + f(x)` chains (ResBlock skip, openaimodel.py:295;
+   * BasicTransformerBlock `+ x`, attention.py:313-319; SpatialTransformer `+ x_in`, :385) in fp32 on its CPU path.  A value v
+   * of such a chain is stored as hi = fp16(v) (what every GEMM / norm consumer reads) plus lo = fp16(v - hi), so that the
+   * next link of the chain adds to hi + lo (~22 significant bits) instead of to a value that was already rounded to fp16:
+   * the rounding of the chain no longer accumulates with depth.  res_lo (fp16 [M][ld_res], may be NULL) is added with res;
+   * out_lo (fp16 [M][ld_out], may be NULL; fp16 `out` only, columns < n_tr_begin) receives fp16(v - fp16(v)). */
+  const void* res_lo;
+  void* out_lo;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);

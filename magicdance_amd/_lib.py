@@ -24,7 +24,7 @@ class IgemmParams(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32), ("out_t", C.c_void_p),
         ("n_tr_begin", C.c_int32), ("ld_t", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("force_cfg", C.c_int32), ("force_splitk", C.c_int32), ("ln_s1", C.c_void_p), ("ln_s0", C.c_void_p),
-        ("ln_eps", C.c_float), ("asym_pad", C.c_int32),
+        ("ln_eps", C.c_float), ("asym_pad", C.c_int32), ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
 
 

@@ -38,9 +38,11 @@ struct IgemmArgs {
   const float* bias;
   long long bias_bs;
   const half_t* res;
+  const half_t* res_lo;
   int ld_res;
   int act;
   void* out;
+  half_t* out_lo;
   int ld_out;
   int out_f32;
   half_t* out_t;
@@ -83,6 +85,11 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
     const h4 rv = *reinterpret_cast<const h4*>(g.res + (long long)m * g.ld_res + n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    if (g.res_lo) {  // second term of the two-term residual stream: the chain value is res + res_lo
+      const h4 rl = *reinterpret_cast<const h4*>(g.res_lo + (long long)m * g.ld_res + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+    }
   }
   if (g.out_f32) {
     *reinterpret_cast<f4*>(reinterpret_cast<float*>(g.out) + (long long)m * g.ld_out + n) = v;
@@ -91,6 +98,12 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
     *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
+    if (g.out_lo) {  // what the fp16 store dropped, for the next link of the residual chain
+      h4 l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[i] = (half_t)(v[i] - (float)o[i]);
+      *reinterpret_cast<h4*>(g.out_lo + (long long)m * g.ld_out + n) = l;
+    }
   }
 }
 
@@ -669,6 +682,8 @@ int validate(const md_igemm_params* p) {
   if (p->n <= 0 || (p->n & 3) || (p->ld_out & 3)) return MD_ERR_BAD_ARG;
   if (p->batch <= 0 || p->hin <= 0 || p->win <= 0 || p->hout <= 0 || p->wout <= 0) return MD_ERR_BAD_ARG;
   if (p->res && (p->ld_res & 3)) return MD_ERR_BAD_ARG;
+  if (p->res_lo && !p->res) return MD_ERR_BAD_ARG;
+  if (p->out_lo && (p->out_f32 || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;
   if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
   if (p->bias_batch_stride & 3) return MD_ERR_BAD_ARG;
@@ -786,6 +801,8 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.bias = p->bias;
   g.bias_bs = p->bias_batch_stride;
   g.res = (const half_t*)p->res;
+  g.res_lo = (const half_t*)p->res_lo;
+  g.out_lo = (half_t*)p->out_lo;
   g.ld_res = p->ld_res;
   g.act = p->act;
   g.out = p->out;

@@ -75,6 +75,10 @@ class Arena:
 
 _ARENAS = {}
 _FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
+# Two-term (hi + lo fp16) residual stream: the `x + f(x)` chains of the ResBlocks / transformer blocks (kept in fp32 by the
+# reference's CPU path) carry the part their fp16 store dropped to the next link, so the chain's rounding does not accumulate
+# with depth (md_igemm res_lo / out_lo).  MD_RES_LO=0 restores the single-term stream (parity / cost A-B).
+_RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
 
 
 def get_arena(device, name=""):
@@ -141,11 +145,12 @@ def fold_layernorm(w, b, gamma, beta, device):
 
 
 class Act:
-    """NHWC fp16 activation handle: tensor [B, H*W, C] + spatial dims."""
-    __slots__ = ("t", "b", "h", "w", "c")
+    """NHWC fp16 activation handle: tensor [B, H*W, C] + spatial dims.  ``lo`` (same shape, fp16, or None) is the second
+    term of a two-term residual-stream value: the chain value is t + lo, every GEMM / norm consumer reads t alone."""
+    __slots__ = ("t", "b", "h", "w", "c", "lo")
 
-    def __init__(self, t, b, h, w, c):
-        self.t, self.b, self.h, self.w, self.c = t, b, h, w, c
+    def __init__(self, t, b, h, w, c, lo=None):
+        self.t, self.b, self.h, self.w, self.c, self.lo = t, b, h, w, c, lo
 
     @property
     def hw(self):
@@ -153,7 +158,7 @@ class Act:
 
     def head(self, nb):
         """first nb samples (batch is the outermost dim, so this is a contiguous prefix)"""
-        return Act(self.t[:nb], nb, self.h, self.w, self.c)
+        return Act(self.t[:nb], nb, self.h, self.w, self.c, None if self.lo is None else self.lo[:nb])
 
 
 class BankKV:
@@ -290,8 +295,9 @@ class NetEngine:
         return buf
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
-             out_f32=False, out=None, ln=None):
-        """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act."""
+             out_f32=False, out=None, ln=None, lo=False):
+        """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act.  ``lo``: the output is a link of
+        a residual chain -- also store what the fp16 rounding dropped (Act.lo), to be added back by the next link."""
         hin, win = x.h, x.w
         if ups:
             hout, wout = 2 * hin, 2 * win
@@ -302,12 +308,13 @@ class NetEngine:
         nout = n // 2 if act == MD_ACT_GEGLU else n
         if out is None:
             out = self.arena.alloc((x.b, hout * wout, nout), F32 if out_f32 else F16)
+        out_lo = self.arena.alloc((x.b, hout * wout, nout), F16) if (lo and _RES_LO and not out_f32) else None
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
-                  out_f32=out_f32, ws=self._ws(), ln=ln)
+                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo)
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
-        return Act(out, x.b, hout, wout, nout)
+        return Act(out, x.b, hout, wout, nout, out_lo)
 
     def _gn_ws(self):
         """GroupNorm partial sums: a small scratch of its own (the igemm workspace starts with arrival counters)."""
@@ -399,11 +406,11 @@ class NetEngine:
         h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total)
         h = self.gn(h, r["gn2"], silu=True)
         if "skip_w" in r:
-            skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"])
+            skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"], lo=True)
         else:
             assert x1 is None
             skip = x
-        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip)
+        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True)
 
     def attention(self, q, ld_q, k0, ld_k0, vt0, ld_vt0, n0, b, nq, heads, dh, *, k0_bs, vt0_bs, seg1=None, n1_batches=0):
         c = heads * dh
@@ -423,7 +430,7 @@ class NetEngine:
         b, n, c, heads, dh = x.b, x.hw, st["inner"], st["heads"], st["dh"]
         a = self.arena
         xn = self.gn(x, st["gn"], eps=1e-6, silu=False)
-        t = self.conv(xn, st["pin_w"], c, k=1, bias=st["pin_b"])
+        t = self.conv(xn, st["pin_w"], c, k=1, bias=st["pin_b"], lo=True)
         ldv = (n + 7) & ~7
         for blk in st["blocks"]:
             if mode == "write":
@@ -467,7 +474,7 @@ class NetEngine:
                 n1b = nread
             att = self.attention(qk, 2 * c, qk[:, :, c:], 2 * c, vt, ldv, n, b, n, heads, dh, k0_bs=n * 2 * c,
                                  vt0_bs=c * ldv, seg1=seg1, n1_batches=n1b)
-            t = self.conv(Act(att, b, 1, n, c), blk["o1_w"], c, k=1, bias=blk["o1_b"], res=Act(t.t, b, 1, n, c))
+            t = self.conv(Act(att, b, 1, n, c), blk["o1_w"], c, k=1, bias=blk["o1_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
             # cross attention to the text context (attention.py:318)
             if "q2_ln" in blk:
                 wl, s1, s0 = blk["q2_ln"]
@@ -480,7 +487,7 @@ class NetEngine:
             assert bc == 1 or bc == b, "context batch must be 1 or match the sample batch"
             att2 = self.attention(q2.t, c, kc, c, vtc, ldvc, tk, b, n, heads, dh, k0_bs=(0 if bc == 1 else tk * c),
                                   vt0_bs=(0 if bc == 1 else c * ldvc))
-            t = self.conv(Act(att2, b, 1, n, c), blk["o2_w"], c, k=1, bias=blk["o2_b"], res=Act(t.t, b, 1, n, c))
+            t = self.conv(Act(att2, b, 1, n, c), blk["o2_w"], c, k=1, bias=blk["o2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
             # GEGLU feed-forward (attention.py:50-77, 319)
             if "ff1_ln" in blk:
                 wl, s1, s0 = blk["ff1_ln"]
@@ -488,9 +495,9 @@ class NetEngine:
             else:
                 n3 = self.ln(t, blk["ln3"])
                 ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
-            t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c))
+            t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
         t = Act(t.t, b, x.h, x.w, c)
-        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x)
+        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True)
 
     def _project_bank(self, blk, bank, k_out, vt_out):
         bb, nb, c = bank.b, bank.hw, bank.c
@@ -518,11 +525,11 @@ class NetEngine:
                 if mode == "read":
                     bank_idx[0] += 1                                               # openaimodel.py:92-93
             elif kind == "down":
-                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"])
+                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"], lo=True)
             elif kind == "up":
                 h = self.conv(h, layer["w"], layer["c"], k=3, ups=1, bias=layer["b"])
             elif kind == "stem":
-                h = self.conv(h, layer["w"], layer["cout"], k=3, bias=layer["b"])
+                h = self.conv(h, layer["w"], layer["cout"], k=3, bias=layer["b"], lo=True)
             else:
                 raise NotImplementedError(kind)
         assert x1 is None

@@ -19,7 +19,7 @@ def _mem(t, size, stride):
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None):
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None):
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -63,7 +63,12 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
         y = y[..., :ntr0]
     if res is not None:
         y = y + _mem(res, (batch, tokens, ntr0), (tokens * ld_res, ld_res, 1)).float()
-    _mem(out, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1)).copy_(y)
+        if res_lo is not None:
+            y = y + _mem(res_lo, (batch, tokens, ntr0), (tokens * ld_res, ld_res, 1)).float()
+    o = _mem(out, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1))
+    o.copy_(y)
+    if out_lo is not None:   # what the fp16 store dropped (two-term residual stream)
+        _mem(out_lo, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1)).copy_(y - o.float())
     return out
 
 

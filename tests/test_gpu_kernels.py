@@ -105,6 +105,32 @@ def test_igemm_splitk_epilogues(dev, splitk):
     assert _err(_nchw32(out, b, h, w), ref) <= 6e-3
 
 
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_igemm_two_term_residual(dev, splitk):
+    """md_igemm res_lo / out_lo (ABI v2): the residual is res + res_lo and out_lo receives what the fp16 store of the result
+    dropped, on the in-kernel epilogue (splitk 1) and on the split-K reduce kernel.  hi + lo must reproduce the fp32 value to
+    ~2^-21 relative (two fp16 terms), far below the 2^-11 of a single fp16 store."""
+    from magicdance_amd import ops, engine
+    b, cin, h, w, cout = 2, 320, 8, 8, 128
+    x = _rand((b, cin, h, w), 1, dev)
+    wt = _rand((cout, cin, 3, 3), 2, dev, (cin * 9) ** -0.5)
+    bias = _rand((cout,), 3, dev, 0.5)
+    res32 = _rand((b, cout, h, w), 4, dev, 3.0)
+    res_hi = _nhwc16(res32)
+    res_lo = (res32.permute(0, 2, 3, 1).reshape(b, h * w, cout) - res_hi.float()).to(F16).contiguous()
+    ref = F.conv2d(x.half().float(), wt.half().float(), bias, padding=1) + _nchw32(res_hi.float() + res_lo.float(), b, h, w)
+    out = torch.empty((b, h * w, cout), dtype=F16, device=dev)
+    out_lo = torch.full((b, h * w, cout), 7.0, dtype=F16, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    ops.igemm(_nhwc16(x), engine.pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=3, bias=bias,
+              res=res_hi, ld_res=cout, res_lo=res_lo, out=out, out_lo=out_lo, ws=ws, force_splitk=splitk)
+    got = _nchw32(out.float() + out_lo.float(), b, h, w)
+    scale = float(ref.abs().max())
+    assert _err(_nchw32(out, b, h, w), ref) <= 1.2e-3 * scale          # hi alone: one fp16 rounding
+    assert _err(got, ref) <= 2e-5 * scale                              # hi + lo: fp32 accumulation-order noise only
+    assert float(out_lo.float().abs().max()) <= 2.0 ** -11 * scale * 1.01
+
+
 def test_igemm_linear_f32_transposed_geglu(dev):
     from magicdance_amd import ops, engine
     b, n, c = 2, 80, 64  # tokens not a multiple of the tile

@@ -50,10 +50,12 @@ def build_model(device, size):
     return model.eval()
 
 
-def cpu_baseline(model, inp, size, z_hip=None, img_hip=None):
+def cpu_baseline(model, inp, size, z_hip=None, img_hip=None, steps=3):
     """The CPU oracle (oracle/restatement.py + oracle/vae_restatement.py, torch fp32) on this box's host cores, bounded
-    sample: ONE DDIM step (cond + uncond apply_model) of the same single-frame workload plus the first-stage decode of
-    one frame; frames/s = 1 / (50 x step + decode)."""
+    sample: the first ``steps`` of the 50 DDIM steps of the same single-frame workload (appearance net, pose ControlNet,
+    UNet read pass, UNet uncond pass -- each timed -- and the CFG / DDIM update) plus the first-stage decode of one frame;
+    frames/s = 1 / (50 x mean step + decode).  The first step's eps pair doubles as a full-size parity check of the HIP path."""
+    import numpy as np
     from oracle import restatement as R
     from oracle import vae_restatement as V
     sd = {}
@@ -62,24 +64,42 @@ def cpu_baseline(model, inp, size, z_hip=None, img_hip=None):
                      ("pose_control_model.", model.pose_control_model)):
         sd.update({pre + k: v.detach().float().cpu() for k, v in mod.state_dict().items()})
     cfg = R.Cfg()
-    c = {"c_concat": [inp["pose"][:1].cpu()], "c_crossattn": [inp["ctx"].cpu()], "image_control": [inp["ref"].cpu()],
-         "wonoise": True, "overlap_sampling": False}
+    ctx, ref, pose = inp["ctx"].cpu().float(), inp["ref"].cpu().float(), inp["pose"][:1].cpu().float()
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
     x = inp["x_T"].cpu()
-    t = torch.full((1,), 981, dtype=torch.long)
+    ts = np.flip(R.make_ddim_timesteps(50))
+    _, alphas, alphas_prev = R.make_ddim_sampling_parameters(R.alphas_cumprod(), R.make_ddim_timesteps(50), 0.0)
     threads = torch.get_num_threads()
+    per = {"appearance": [], "pose": [], "unet_read": [], "unet_uc": []}
+    parity = None
     with torch.no_grad():
-        t0 = time.time()
-        e_c = R.apply_model(sd, cfg, x, t, c, inp["ref"].cpu())
-        e_u = R.apply_model(sd, cfg, x, t, c, None, uc=True)
-        dt = time.time() - t0
-        # the oracle outputs double as a full-size parity check of the HIP path on the same inputs (checker only)
-        dev = inp["x_T"].device
-        cd = {k: ([v.to(dev) for v in vv] if isinstance(vv, list) else vv) for k, vv in c.items()}
-        h_c = model.apply_model(inp["x_T"], t.to(dev), cd, inp["ref"]).cpu()
-        h_u = model.apply_model(inp["x_T"], t.to(dev), cd, None, uc=True).cpu()
-        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
-        parity = {"eps_cond_rel_max_abs": rel(h_c, e_c), "eps_uncond_rel_max_abs": rel(h_u, e_u),
-                  "note": "HIP fp16 path vs fp32 CPU oracle, t=981, same synthetic weights/inputs"}
+        for i in range(steps):
+            t = torch.full((1,), int(ts[i]), dtype=torch.long)
+            index = 50 - i - 1
+            t0 = time.time()
+            banks = R.appearance_forward(sd, R.APP, cfg, ref, t, ctx)
+            t1 = time.time()
+            pr = R.pose_forward(sd, R.POSE, cfg, x, pose, t, ctx)
+            t2 = time.time()
+            e_c = R.unet_forward(sd, R.UNET, cfg, x, t, ctx, banks, pr, False, False)
+            t3 = time.time()
+            e_u = R.unet_forward(sd, R.UNET, cfg, x, t, ctx, [], None, True, False)
+            t4 = time.time()
+            for k, v in zip(per, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                per[k].append(v)
+            if i == 0:
+                # the oracle outputs double as a full-size parity check of the HIP path on the same inputs (checker only)
+                dev = inp["x_T"].device
+                cd = {k: ([v.to(dev) for v in vv] if isinstance(vv, list) else vv) for k, vv in c.items()}
+                h_c = model.apply_model(inp["x_T"], t.to(dev), cd, inp["ref"]).cpu()
+                h_u = model.apply_model(inp["x_T"], t.to(dev), cd, None, uc=True).cpu()
+                rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+                parity = {"eps_cond_rel_max_abs": rel(h_c, e_c), "eps_uncond_rel_max_abs": rel(h_u, e_u),
+                          "note": f"HIP fp16 path vs fp32 CPU oracle, t={int(ts[0])}, same synthetic weights/inputs"}
+            e = e_u + 7.0 * (e_c - e_u)
+            a_t, a_p = float(alphas[index]), float(alphas_prev[index])
+            x = (a_p ** 0.5) * (x - (1.0 - a_t) ** 0.5 * e) / (a_t ** 0.5) + (1.0 - a_p) ** 0.5 * e
+        dt = sum(sum(v) for v in per.values()) / steps
         dt_vae = 0.0
         if z_hip is not None:
             pre = "first_stage_model."
@@ -89,8 +109,9 @@ def cpu_baseline(model, inp, size, z_hip=None, img_hip=None):
             dt_vae = time.time() - t0
             parity["decode_rel_max_abs"] = rel(img_hip[:1].cpu(), img)
     return {"value": 1.0 / (50.0 * dt + dt_vae), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 of 50 DDIM steps (cond+uncond apply_model, 1 frame {8 * size}x{8 * size}) = {dt:.1f}s, x50 extrapolated"
+            "sample": f"first {steps} of 50 DDIM steps (1 frame {8 * size}x{8 * size}), mean {dt:.1f} s/step, x50 extrapolated"
                       + (f", + first-stage decode of the frame = {dt_vae:.1f}s" if z_hip is not None else ""),
+            "s_per_step": {k: sum(v) / len(v) for k, v in per.items()}, "s_per_step_total": dt, "decode_s": dt_vae,
             "parity_full_size": parity}
 
 
@@ -99,7 +120,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5, help="timed frame-batches (each = a full DDIM loop)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--frames-per-gpu", type=int, default=None,
+                    help="frames per GPU per batch; default 1 at --gpus 1 (BASELINE configs[1]), 8 at --gpus N > 1 (configs[3]: "
+                         "8 frames per GPU as one batch, 64 frames on 8 GPUs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra configs[2] line (8 frames as one batch) at --gpus 1")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--size", type=int, default=64, help="latent side (64 = 512x512)")
     ap.add_argument("--sequence", type=int, default=0,
@@ -124,7 +148,8 @@ def main():
     from magicdance_amd import synthetic, ops
     from magicdance_amd import parallel
     model = build_model(dev, args.size)
-    fpg = args.frames_per_gpu
+    fpg = args.frames_per_gpu if args.frames_per_gpu else (1 if world == 1 else 8)
+    cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get((fpg, world), "configs[3]" if (fpg == 8 and world > 1) else "custom")
     inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
     runner = parallel.FrameShardedSampler(model, rank=rank, world=world)
     my = slice(rank * fpg, (rank + 1) * fpg)
@@ -163,7 +188,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
            "ms_per_ddim_step": 1e3 * dt / args.steps / args.ddim_steps,
            "config": {"workload": (f"sequence of {args.sequence} frames/GPU sharing one reference (bank table once per sequence), "
-                                   f"batches of {fpg}, " if args.sequence else f"configs[1]: {fpg} frame(s)/GPU ") +
+                                   f"batches of {fpg}, " if args.sequence else f"{cfg_name}: {fpg} frame(s)/GPU as one batch, ") +
                                   f"{8 * args.size}x{8 * args.size}, {args.ddim_steps}-step DDIM, "
                                   "appearance + pose ControlNet + UNet cond/uncond, CFG 7, latents in -> " +
                                   ("latents out" if args.no_decode else "first-stage-decoded frames out"),
@@ -177,14 +202,16 @@ def main():
         ig = fam["igemm"]
         ig_ms = ig.get("graph_ms", ig["ms"])
         ach = ig["flops"] / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        # command, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))
-            traffic = pmc.get("igemm_hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            pass
+        # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS
+        # workload -- the 50-step batch --, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
+        traffic, traffic_src = None, None
+        for cand in ("round2_pmc_summary.json", "round1_pmc_summary.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), cand
+                break
+            except Exception:  # noqa: BLE001
+                pass
 
         def part(d):
             if d is None:
@@ -194,7 +221,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one batch: reference-KV table pass + "
                            f"{ig['ddim_steps']} DDIM steps" + ("" if args.no_decode else " + first-stage decode") + ")", "achieved": ach,
                            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "bytes/launch (PMC, profiles/round1_pmc_summary.json)",
+                           "traffic_unit": f"bytes/launch (PMC, profiles/{traffic_src})",
                            "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
                            "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,
@@ -207,6 +234,27 @@ def main():
                                             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
                                             "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
                                         for k, v in fam.items()}
+    if rank == 0 and not args.no_roofline:
+        # metric (ii), "UNet ms/step": one forward of each network at B = 1 and B = 8, graph-replayed between HIP events
+        nets = {}
+        for bb in (1, 8):
+            pi = synthetic.synth_inputs((args.size, args.size), frames=bb, seed=0, device=dev)
+            nets[f"B{bb}"] = runner.network_pass_times(pi["pose"], ctx, ref, pi["x_T"].repeat(bb, 1, 1, 1), ddim_steps=args.ddim_steps)
+        out["unet_ms_per_step"] = nets
+    if rank == 0 and world == 1 and fpg == 1 and not args.sequence and not args.no_extra:
+        # extra line: BASELINE configs[2] (8 frames as one batch on one GPU), same timing protocol, 1 warm-up + 2 timed batches
+        p8 = synthetic.synth_inputs((args.size, args.size), frames=8, seed=0, device=dev)
+        x8 = p8["x_T"].repeat(8, 1, 1, 1)
+        runner.sample(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(2):
+            runner.sample(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
+        torch.cuda.synchronize()
+        d8 = (time.time() - t0) / 2
+        out["extra"] = {"configs[2]": {"workload": "8 frames as one batch, 512x512, 50-step DDIM, decoded frames out", "value": 8 / d8,
+                                       "unit": "frames/s", "ms_per_step": 1e3 * d8, "ms_per_ddim_step": 1e3 * d8 / args.ddim_steps,
+                                       "steps": 2, "warmup": 1}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         z_one = runner.sample(pose[:1], ctx, ref, x_T[:1], ddim_steps=args.ddim_steps, scale=7.0) if not args.no_decode else None
         out["cpu_baseline"] = cpu_baseline(model, inp, args.size, z_one,
@@ -214,6 +262,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()   # rank 0 may still have been profiling: leave the group together
         dist.destroy_process_group()
 
 

@@ -171,14 +171,19 @@ int md_timestep_embedding(const float* t, float* out, int32_t nt, int32_t dim, f
  * time_embed MLP cldm/cldm.py:66-68). */
 int md_gemv_f32(const float* x, const void* w, const float* bias, float* y, int32_t rows, int32_t k, int32_t n,
                 int32_t act_in, void* stream);
-/* rows of a table -> fixed "current step" buffer: dst[i] = table[row*width + i]  (fp32) */
-int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, float* dst,
+/* rows of a table -> fixed "current step" buffer: dst[i] = table[row*width + i]  (fp32), row = *row_counter + row_offset
+ * clamped to [0, nrows) (the counter is advanced by every replay of a captured step graph). */
+int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, int32_t nrows, float* dst,
                       int32_t width, void* stream);
-/* Multi-segment row gather (the per-step pick of the reference-KV table, SURVEY 8(e) collective 1): for every segment
- * s, dst[dst_off_s ..+len_s) = table[tab_off_s + row*len_s ..+len_s), row = *row_counter + row_offset.
- * seg: device int64 [nseg][3] = (tab_off, len, dst_off), all in 16-byte units; max_row_units = max len. */
+/* Multi-segment row gather (the per-step pick of the reference-KV table, SURVEY 8(e) collective 1).  The table is laid out
+ * [row block][segment][rows_per_block][len_s] so that a block of consecutive DDIM rows -- the output of one batched appearance
+ * pass, and one rank's contribution to the RCCL all-gather -- is ONE contiguous piece of block_units 16-byte units.  For every
+ * segment s: dst[dst_off_s ..+len_s) = table[(row / rows_per_block) * block_units + seg_off_s + (row % rows_per_block) * len_s
+ * ..+len_s), row = *row_counter + row_offset clamped to [0, nrows).
+ * seg: device int64 [nseg][3] = (seg_off inside a block, len, dst_off), all in 16-byte units; max_row_units = max len. */
 int md_gather_rows(const void* table, const int64_t* seg, int32_t nseg, int64_t max_row_units,
-                   const int32_t* row_counter, int32_t row_offset, void* dst, void* stream);
+                   const int32_t* row_counter, int32_t row_offset, int32_t nrows, int32_t rows_per_block,
+                   int64_t block_units, void* dst, void* stream);
 /* increments *counter by 1 (device side), used to advance the DDIM step inside a captured graph */
 int md_counter_add(int32_t* counter, int32_t delta, void* stream);
 

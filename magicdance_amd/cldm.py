@@ -207,6 +207,13 @@ class ControlLDMReferenceOnlyPose(nn.Module):
         if not any(p.startswith("cond_stage_model") for p in drop):
             state_dict = adapt_clip_keys(state_dict, set(self.state_dict().keys()))
         self._fused = None
+        # nn.Module.load_state_dict recurses through _load_from_state_dict, not through the children's load_state_dict
+        # overrides: drop every packed-fp16 engine here, or a second checkpoint would render with the first one's weights
+        for m in self.modules():
+            if hasattr(m, "invalidate_engine"):
+                m.invalidate_engine()
+            elif hasattr(m, "_engine") and hasattr(m, "md_engine"):
+                m._engine = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     # ------------------------------------------------------------------ VAE / CLIP glue (the VAE is magicdance_amd.autoencoder)

@@ -96,22 +96,27 @@ __global__ __launch_bounds__(256) void gemv_f32(const float* __restrict__ x, con
   }
 }
 
-__global__ void select_row_f32(const float* __restrict__ table, const int* __restrict__ counter, int row_offset,
+// The row index comes from a device-side counter that a captured step graph advances on every replay: it is clamped to the
+// table ([0, nrows)), so a replay past the last step re-reads the last row instead of running off the end of the table.
+__global__ void select_row_f32(const float* __restrict__ table, const int* __restrict__ counter, int row_offset, int nrows,
                                float* __restrict__ dst, int width) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= width) return;
-  const int row = (counter ? *counter : 0) + row_offset;
+  const int row = min(max((counter ? *counter : 0) + row_offset, 0), nrows - 1);
   dst[i] = table[(long long)row * width + i];
 }
 
-// one blockIdx.y per segment; seg = (table offset, row length, dst offset) in 16-byte units
+// one blockIdx.y per segment; seg = (offset of the segment inside a row block, row length, dst offset) in 16-byte units.
+// Table layout: [row block][segment][rows_per_block][row length]: a block of rows_per_block consecutive DDIM rows is one
+// contiguous piece of memory (what one batched appearance pass produces, and what one rank contributes to an all-gather).
 __global__ __launch_bounds__(256) void gather_rows(const uint4* __restrict__ table, const long long* __restrict__ seg,
-                                                   const int* __restrict__ counter, int row_offset,
-                                                   uint4* __restrict__ dst) {
+                                                   const int* __restrict__ counter, int row_offset, int nrows,
+                                                   int rows_per_block, long long block_units, uint4* __restrict__ dst) {
   const long long* sg = seg + 3 * blockIdx.y;
   const long long len = sg[1];
-  const int row = (counter ? *counter : 0) + row_offset;
-  const uint4* src = table + sg[0] + (long long)row * len;
+  const int row = min(max((counter ? *counter : 0) + row_offset, 0), nrows - 1);
+  const int blk = row / rows_per_block, within = row - blk * rows_per_block;
+  const uint4* src = table + (long long)blk * block_units + sg[0] + (long long)within * len;
   uint4* d = dst + sg[2];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long long)gridDim.x * 256) d[i] = src[i];
 }
@@ -211,26 +216,28 @@ extern "C" int md_gemv_f32(const float* x, const void* w, const float* bias, flo
   return MD_OK;
 }
 
-extern "C" int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, float* dst,
-                                 int32_t width, void* stream) {
-  if (!table || !dst || width <= 0) return MD_ERR_BAD_ARG;
+extern "C" int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t row_offset, int32_t nrows,
+                                 float* dst, int32_t width, void* stream) {
+  if (!table || !dst || width <= 0 || nrows <= 0) return MD_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)width * 8.0);
-  hipLaunchKernelGGL(select_row_f32, dim3((width + 255) / 256), dim3(256), 0, s, table, row_counter, row_offset, dst,
+  hipLaunchKernelGGL(select_row_f32, dim3((width + 255) / 256), dim3(256), 0, s, table, row_counter, row_offset, nrows, dst,
                      width);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
 
 extern "C" int md_gather_rows(const void* table, const int64_t* seg, int32_t nseg, int64_t max_row_units,
-                              const int32_t* row_counter, int32_t row_offset, void* dst, void* stream) {
-  if (!table || !seg || !dst || nseg <= 0 || max_row_units <= 0) return MD_ERR_BAD_ARG;
+                              const int32_t* row_counter, int32_t row_offset, int32_t nrows, int32_t rows_per_block,
+                              int64_t block_units, void* dst, void* stream) {
+  if (!table || !seg || !dst || nseg <= 0 || max_row_units <= 0 || nrows <= 0 || rows_per_block <= 0 || block_units < 0)
+    return MD_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, 0.0);
   long long gx = (max_row_units + 1023) / 1024;  // ~4 units per thread
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(gather_rows, dim3((unsigned)gx, (unsigned)nseg), dim3(256), 0, s, (const uint4*)table,
-                     (const long long*)seg, row_counter, row_offset, (uint4*)dst);
+                     (const long long*)seg, row_counter, row_offset, nrows, rows_per_block, (long long)block_units, (uint4*)dst);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }

@@ -644,11 +644,15 @@ int g_default_loader = [] {
 template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
+  if (lds > 65536) {
+    int devi = 0;
+    MD_HIP_CHECK(hipGetDevice(&devi));
+    if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (devi >= 0 && devi < 64) attr_set[devi] = true;
+    }
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>), grid, dim3(256), lds, s, g);

@@ -13,6 +13,7 @@ Mirror of ``DDIMSampler_ReferenceOnly`` (model_lib/ControlNet/ldm/models/diffusi
     device-side counter, so 50 steps are 50 graph launches with no host work in between.
 """
 import os
+import random
 
 import numpy as np
 import torch
@@ -133,9 +134,27 @@ class DDIMSampler_ReferenceOnly(object):
                 else:
                     c_in[k] = c[k]
             eps_u, eps_c = model.apply_model_nhwc(x_in, t_in, c_in, ref_in).chunk(2)
+        elif c.get("overlap_sampling"):                                                              # :569-594
+            # temporal overlap sampling: windows of 16 frames, stride 12, starting at a random frame offset (python
+            # ``random``, as the reference draws it); classifier-free guidance per window, predictions accumulated per frame
+            # and divided by the visit count.  Stays on the device (the reference round-trips through the CPU, :570-592).
+            nf = c["c_concat"][0].shape[0]
+            offset = random.randint(0, nf - 1)
+            hw = x.shape[2] * x.shape[3]
+            pred_all = torch.zeros((nf, hw, 4), dtype=F32, device=device)
+            counts = torch.zeros((nf,), dtype=F32, device=device)
+            for start_idx in range(offset, offset + nf - 16 + 1 + 12, 12):
+                idx = (torch.arange(start_idx, start_idx + 16) % nf).to(device)
+                c_w = dict(c)
+                c_w["c_concat"] = [c["c_concat"][0][idx].contiguous()]
+                ref_w = reference_image_noisy if reference_image_noisy.shape[0] != nf else reference_image_noisy[idx]
+                x_w, t_w = x[idx].contiguous(), (t[idx] if t.shape[0] == nf else t[:16])
+                m_t = model.apply_model_nhwc(x_w, t_w, c_w, ref_w).clone()
+                m_u = model.apply_model_nhwc(x_w, t_w, c_w, None, uc=True)
+                pred_all.index_add_(0, idx, (m_u + unconditional_guidance_scale * (m_t - m_u))[..., :4])
+                counts.index_add_(0, idx, torch.ones_like(idx, dtype=F32))
+            eps_c, eps_u = (pred_all / counts.reshape(-1, 1, 1)).contiguous(), None   # guidance already applied
         else:                                                                                        # :595-605
-            if c.get("overlap_sampling"):
-                raise NotImplementedError("overlap_sampling (temporal window) is not reachable from the entry points")
             eps_c = model.apply_model_nhwc(x, t, c, reference_image_noisy).clone()   # arena is rewound below
             eps_u = model.apply_model_nhwc(x, t, c, None, uc=True)
         coef = torch.tensor([self.ddim_alphas[index], self.ddim_alphas_prev[index], self.ddim_sigmas[index],
@@ -179,40 +198,17 @@ class DDIMSampler_ReferenceOnly(object):
         with torch.cuda.stream(st.stream):
             table = os.environ.get("MD_BANK_MODE", "table") != "inline"
             st.prepare(c, img, self, scale, table_mode=table)
-            # The table pass runs AHEAD of the loop on its own stream (own arena / workspaces): step i only needs row i,
-            # and the big-batch appearance GEMMs of chunk k+1 fill the CUs that the small launches of chunk k's steps
-            # leave idle.  Host order = chunk k+1's launches, then chunk k's graph launches.
-            chunks = st.bank_chunks(total) if table else [(0, total)]
-            overlap = table and os.environ.get("MD_TABLE_OVERLAP", "1") != "0"
 
-            def enqueue(k):
-                if not overlap:
-                    st.compute_bank_rows(range(*chunks[k]))
-                    return None
-                with torch.cuda.stream(st.table_stream):
-                    st.compute_bank_rows(range(*chunks[k]))
-                    ev = torch.cuda.Event()
-                    ev.record(st.table_stream)
-                return ev
-
-            if overlap:
-                st.table_stream.wait_stream(st.stream)   # the previous frame's steps are done with the table; inputs are in place
-            ev = enqueue(0) if table else None
-            for k, (r0, r1) in enumerate(chunks):
-                ev_next = enqueue(k + 1) if table and k + 1 < len(chunks) else None
-                if ev is not None:
-                    st.stream.wait_event(ev)
-                ev = ev_next
-                for i in range(r0, r1):
-                    st.step()
-                    index = total - i - 1
-                    if callback:
-                        callback(i)
-                    if img_callback:
-                        img_callback(st.pred_x0.clone(), i)
-                    if index % log_every_t == 0 or index == total - 1:
-                        intermediates["x_inter"].append(st.x.clone())
-                        intermediates["pred_x0"].append(st.pred_x0.clone())
+            def on_step(i):
+                index = total - i - 1
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(st.pred_x0.clone(), i)
+                if index % log_every_t == 0 or index == total - 1:
+                    intermediates["x_inter"].append(st.x.clone())
+                    intermediates["pred_x0"].append(st.pred_x0.clone())
+            st.run_steps(on_step=on_step)
             out = st.x.clone()
         caller.wait_stream(st.stream)
         return out, intermediates
@@ -250,14 +246,30 @@ class FusedStepRunner:
         self.bank_events = None
         self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
         self.table_stream = torch.cuda.Stream(device=model.device)      # the table pass overlaps the first steps of the loop
+        self.table_chunks = int(os.environ.get("MD_TABLE_CHUNKS", "2"))  # sharded: all-gathers per table (2nd overlaps the loop)
+        self.tkey = None
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
 
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
 
-    def prepare(self, c, x_T, sampler, scale, table_mode=False, table_rows=None):
-        """``table_rows`` >= S: rows allocated per table segment (frame sharding pads S to a multiple of the world size so
-        that every rank owns an equal block and the exchange is one all-gather per segment)."""
+    def plan_table(self, S, bref, world=1):
+        """(rows per block, blocks) of the reference-KV table.  A block = ``per`` consecutive DDIM rows = one contiguous piece
+        of memory: what one batched appearance pass produces and, sharded, what one rank contributes to a chunk's all-gather
+        (chunk k = blocks [k*world, (k+1)*world), block k*world + r computed by rank r).  world 1: per = the appearance batch
+        (``bank_chunk`` samples); world > 1: S rows split into ``table_chunks`` all-gathers so that the second one overlaps the
+        first steps of the loop."""
+        if world == 1:
+            per = max(1, min(S, self.bank_chunk // bref))
+        else:
+            per = max(1, -(-S // (world * max(1, self.table_chunks))))
+        nblocks = -(-(-(-S // per)) // world) * world
+        return per, nblocks
+
+    def prepare(self, c, x_T, sampler, scale, table_mode=False, world=1):
+        """Per-batch buffers (x, pose features, schedule tables; keyed on the batch geometry) and -- in table mode -- the
+        reference-KV table (keyed on the reference / schedule geometry only, so a sequence sampled in batches of different
+        sizes keeps one table)."""
         model, dev = self.model, self.model.device
         app, pose_e, unet = model.engines()
         b, cch, hh, ww = x_T.shape
@@ -281,11 +293,16 @@ class FusedStepRunner:
         self.kv_unet = unet.context_kv(self._ctx_unet)
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
-        rows = S if table_rows is None else max(int(table_rows), S)
-        key = (b, cch, hh, ww, S, rows, ref.shape[0], tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
+        bref = ref.shape[0]
+        key = (b, cch, hh, ww, S, bref, tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
                self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
         if key != self.key:
-            self._allocate(key, b, cch, hh, ww, S, ref.shape[0], table_mode, rows)
+            self._allocate(key, b, cch, hh, ww, S, bref, table_mode)
+        if table_mode:
+            per, nblocks = self.plan_table(S, bref, world)
+            tkey = (cch, hh, ww, S, bref, per, nblocks)
+            if tkey != self.tkey:
+                self._allocate_table(tkey, hh, ww, S, bref, per, nblocks)
         self.ref.copy_(ref)
         self.x.copy_(x_T)
         hf = pose_e.hint_features(hint)
@@ -307,13 +324,11 @@ class FusedStepRunner:
             self.graph.destroy()
             self.graph = None
 
-    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode, rows=None):
-        from .nets import bank_shapes
+    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
         dev = self.model.device
         self._drop_graph()
         self.key, self.table_mode = key, table_mode
         self.b, self.cch, self.hw, self.S = b, cch, hh * ww, S
-        R = self.table_rows = S if rows is None else rows
         self.x = torch.empty((b, cch, hh, ww), dtype=F32, device=dev)
         self.pred_x0 = torch.empty_like(self.x)
         self.ref = torch.empty((bref, cch, hh, ww), dtype=F32, device=dev)
@@ -323,92 +338,162 @@ class FusedStepRunner:
         self.t_cur = torch.empty((2 * b,), dtype=F32, device=dev)
         self.coef_cur = torch.empty((5,), dtype=F32, device=dev)
         self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.bank_table = self.bank_cur = None
-        if table_mode:
-            from .engine import BankKV
-            app = self.model.engines()[0]
-            self.bank_geo, segs, toff, coff = [], [], 0, 0
-            for n, c in bank_shapes(app.cfg, (hh, ww)):
-                ldv = (n + 7) & ~7
-                lk, lv = bref * n * c, bref * c * ldv
-                self.bank_geo.append((toff, toff + R * lk, coff, coff + lk, n, c, ldv))
-                segs += [(toff // 8, lk // 8, coff // 8), ((toff + R * lk) // 8, lv // 8, (coff + lk) // 8)]
-                toff += R * (lk + lv)
-                coff += lk + lv
-            self.bank_table = torch.zeros((toff,), dtype=F16, device=dev)   # zeros: the V^T pad columns stay zero
-            self.bank_cur = torch.zeros((coff,), dtype=F16, device=dev)
-            self.bank_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
-            self.bank_seg_max = max(sg[1] for sg in segs)
-            self.bank_cur_kv = [BankKV(self.bank_cur[ck:ck + bref * n * c].view(bref, n, c),
-                                       self.bank_cur[cv:cv + bref * c * ldv].view(bref, c, ldv), bref, n, c, ldv)
-                                for (_, _, ck, cv, n, c, ldv) in self.bank_geo]
-            self._bank_tmp = None
 
-    def table_slabs(self, r0, r1):
-        """The contiguous pieces of ``bank_table`` that hold DDIM rows [r0, r1) (two per bank entry: K and V^T)."""
-        bref, out = self.ref.shape[0], []
-        for tk, tv, _, _, n, c, ldv in self.bank_geo:
+    def _allocate_table(self, tkey, hh, ww, S, bref, per, nblocks):
+        """Reference-KV table, layout [row block][segment][per rows][row length]; segment 2e = K of bank entry e
+        ([bref, n, c] per row), 2e + 1 = its V^T ([bref, c, ldv] per row, pad columns stay zero)."""
+        from .engine import BankKV
+        from .nets import bank_shapes
+        dev = self.model.device
+        self._drop_graph()
+        self.tkey, self.per, self.nblocks = tkey, per, nblocks
+        app = self.model.engines()[0]
+        self.bank_geo, segs, boff, coff = [], [], 0, 0
+        for n, c in bank_shapes(app.cfg, (hh, ww)):
+            ldv = (n + 7) & ~7
             lk, lv = bref * n * c, bref * c * ldv
-            out += [self.bank_table[tk + r0 * lk:tk + r1 * lk], self.bank_table[tv + r0 * lv:tv + r1 * lv]]
-        return out
+            self.bank_geo.append((boff, boff + per * lk, coff, coff + lk, n, c, ldv))
+            segs += [(boff // 8, lk // 8, coff // 8), ((boff + per * lk) // 8, lv // 8, (coff + lk) // 8)]
+            boff += per * (lk + lv)
+            coff += lk + lv
+        self.block_elems = boff
+        self.bank_table = torch.zeros((nblocks * boff,), dtype=F16, device=dev)   # zeros: the V^T pad columns stay zero
+        self.bank_cur = torch.zeros((coff,), dtype=F16, device=dev)
+        self.bank_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
+        self.bank_seg_max = max(sg[1] for sg in segs)
+        self.bank_cur_kv = [BankKV(self.bank_cur[ck:ck + bref * n * c].view(bref, n, c),
+                                   self.bank_cur[cv:cv + bref * c * ldv].view(bref, c, ldv), bref, n, c, ldv)
+                            for (_, _, ck, cv, n, c, ldv) in self.bank_geo]
+        self._bank_tmp = None
 
-    def bank_chunks(self, S):
-        """[(r0, r1)] row blocks of one batched appearance pass each."""
-        per = max(1, self.bank_chunk // self.ref.shape[0])
-        return [(r0, min(S, r0 + per)) for r0 in range(0, S, per)]
+    def table_block(self, blk, count=1):
+        """flat view of ``count`` consecutive row blocks (contiguous memory)"""
+        return self.bank_table[blk * self.block_elems:(blk + count) * self.block_elems]
+
+    def _row_views(self, e, r0, tc):
+        """K [tc*bref, n, c] and V^T [tc*bref, c, ldv] of bank entry e for DDIM rows [r0, r0 + tc) (inside ONE block)."""
+        koff, voff, _, _, n, c, ldv = self.bank_geo[e]
+        bref = self.ref.shape[0]
+        lk, lv = bref * n * c, bref * c * ldv
+        blk, within = divmod(r0, self.per)
+        assert within + tc <= self.per
+        base = blk * self.block_elems
+        return (self.bank_table[base + koff + within * lk:base + koff + (within + tc) * lk].view(tc * bref, n, c),
+                self.bank_table[base + voff + within * lv:base + voff + (within + tc) * lv].view(tc * bref, c, ldv))
 
     def compute_bank_rows(self, rows):
         """Fill the reference-KV table for DDIM steps ``rows`` (indices into the flipped timestep order): the appearance
-        net runs on ``bank_chunk`` timesteps per pass (sample = (step, ref) pair, per-sample time embedding), then the
-        UNet's to_k / to_v project each of the 16 bank tensors for the whole chunk straight into the table.
+        net runs on up to ``bank_chunk`` timesteps per pass (sample = (step, ref) pair, per-sample time embedding), then the
+        UNet's to_k / to_v project each of the 16 bank tensors for the whole pass straight into the table.
         Runs on the current stream with its own arena and split-K workspaces, so it may overlap a step graph that reads
         rows already finished."""
         from .engine import Act, get_arena
         app, _, unet = self.model.engines()
         rows = list(rows)
         bref = self.ref.shape[0]
-        per = max(1, self.bank_chunk // bref)
+        per_pass = max(1, self.bank_chunk // bref)
         step_arena, app.arena = app.arena, get_arena(self.x.device, "table")
         app.ws_slot, unet.ws_slot = 3, 3
         try:
             i = 0
             while i < len(rows):
                 j = i + 1
-                while j < len(rows) and j - i < per and rows[j] == rows[j - 1] + 1:
+                while (j < len(rows) and j - i < per_pass and rows[j] == rows[j - 1] + 1
+                       and rows[j] // self.per == rows[i] // self.per):
                     j += 1
                 r0, tc = rows[i], j - i
                 i = j
                 nb = tc * bref
                 if self._bank_tmp is None or self._bank_tmp[0] < nb:
-                    self._bank_tmp = (per * bref, [torch.empty((per * bref, n, c), dtype=F16, device=self.x.device)
-                                                   for (_, _, _, _, n, c, _) in self.bank_geo])
+                    self._bank_tmp = (per_pass * bref, [torch.empty((per_pass * bref, n, c), dtype=F16, device=self.x.device)
+                                                        for (_, _, _, _, n, c, _) in self.bank_geo])
                 tmp = [Act(t[:nb], nb, 1, t.shape[1], t.shape[2]) for t in self._bank_tmp[1]]
                 app.arena.reset()
                 t_dev = self.ts_table[r0:r0 + tc, 0].repeat_interleave(bref).contiguous()
                 x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
                 app.appearance(x, t_dev, self.kv_app, bank_out=tmp)
-                for e, (tk, tv, _, _, n, c, ldv) in enumerate(self.bank_geo):
-                    lk, lv = bref * n * c, bref * c * ldv
-                    unet.project_bank(e, tmp[e], self.bank_table[tk + r0 * lk:tk + (r0 + tc) * lk].view(nb, n, c),
-                                      self.bank_table[tv + r0 * lv:tv + (r0 + tc) * lv].view(nb, c, ldv))
+                for e in range(len(self.bank_geo)):
+                    k_out, vt_out = self._row_views(e, r0, tc)
+                    unet.project_bank(e, tmp[e], k_out, vt_out)
         finally:
             app.arena = step_arena
             app.ws_slot, unet.ws_slot = 0, 0
+
+    # ------------------------------------------------------------------ table chunks / step loop
+    def n_chunks(self, world=1):
+        return self.nblocks // world
+
+    def chunk_rows(self, k, world=1):
+        r0 = k * world * self.per
+        return min(self.S, r0), min(self.S, r0 + world * self.per)
+
+    def enqueue_chunk(self, k, rank=0, world=1, group=None):
+        """Chunk k of the reference-KV table on the current stream: this rank's block (one batched appearance pass + the bank
+        K / V^T projections), then -- sharded -- ONE RCCL all-gather of the chunk's ``world`` contiguous blocks, in place (the
+        send buffer is this rank's block inside the receive buffer; every point-to-point xGMI link carries a different block at
+        the same time).  Every rank issues the same collectives in the same order, whatever its own frame count."""
+        blk = k * world + rank
+        r0, r1 = min(self.S, blk * self.per), min(self.S, (blk + 1) * self.per)
+        if r1 > r0:
+            self.compute_bank_rows(range(r0, r1))
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.table_block(k * world, world), self.table_block(blk), group=group)
+
+    def run_steps(self, rank=0, world=1, group=None, on_step=None, fill=True, steps=True):
+        """The S-step loop on ``self.stream`` (current).  In table mode the table is (``fill``) produced chunk by chunk on
+        ``table_stream`` AHEAD of the loop: chunk k + 1 (appearance pass and, sharded, its all-gather) is enqueued before the
+        step graphs of chunk k, which wait on chunk k's event -- step i only needs row i, and the big launches of the table pass
+        fill the CUs that the small launches of a step leave idle.  ``steps=False``: fill only (a rank with no frames still takes
+        part in the collectives)."""
+        S = self.S
+        if not (self.table_mode and fill):
+            for i in range(S if steps else 0):
+                self.step()
+                if on_step:
+                    on_step(i)
+            return
+        overlap = os.environ.get("MD_TABLE_OVERLAP", "1") != "0"
+
+        def enqueue(k):
+            if not overlap:
+                self.enqueue_chunk(k, rank, world, group)
+                return None
+            with torch.cuda.stream(self.table_stream):
+                self.enqueue_chunk(k, rank, world, group)
+                ev = torch.cuda.Event()
+                ev.record(self.table_stream)
+            return ev
+
+        if overlap:
+            self.table_stream.wait_stream(torch.cuda.current_stream())   # earlier steps are done with the table; inputs in place
+        nch = self.n_chunks(world)
+        ev = enqueue(0)
+        for k in range(nch):
+            ev_next = enqueue(k + 1) if k + 1 < nch else None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            ev = ev_next
+            r0, r1 = self.chunk_rows(k, world)
+            for i in range(r0, r1 if steps else r0):
+                self.step()
+                if on_step:
+                    on_step(i)
 
     def _launch_sequence(self):
         """One DDIM step as a fixed launch sequence on fixed addresses."""
         model = self.model
         app, pose_e, unet = model.engines()
         b = self.b
-        ops.select_row_f32(self.ts_table, self.counter, 0, self.t_cur, 2 * b)
-        ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5)
+        ops.select_row_f32(self.ts_table, self.counter, 0, self.t_cur, 2 * b, self.S)
+        ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5, self.S)
         arena = unet.arena
         arena.reset()
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
         if self.table_mode:
             ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
-                            self.bank_cur)
+                            self.bank_cur, self.S, self.per, self.block_elems // 8)
         if self.overlap == 3:
             s_app, s_pose, _ = self.side
             if self.table_mode:
@@ -498,7 +583,11 @@ class FusedStepRunner:
             arena.frozen = True
             try:
                 g.begin()
-                self._launch_sequence()
+                try:
+                    self._launch_sequence()
+                except BaseException:
+                    g.abort()   # leave the stream out of capture mode (a failed launch must not poison every later one)
+                    raise
                 g.end()
             finally:
                 arena.frozen = False

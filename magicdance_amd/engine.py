@@ -356,9 +356,14 @@ class NetEngine:
     def context_kv(self, ctx):
         """Cross-attention K / V^T of every transformer block for a text context [Bc, T, ctx_dim] (fp32/fp16 torch
         tensor).  Step- and frame-invariant, so cached per context tensor (attention.py:171-174 to_k/to_v)."""
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
-        if self._ctx_cache is not None and self._ctx_cache[0] == key:
-            return self._ctx_cache[1]
+        # keyed on CONTENT (the generic route builds a fresh torch.cat per call, so an address key would never hit, and a freed
+        # tensor's address can be reused by different data): compare against the retained source tensor
+        if self._ctx_cache is not None:
+            (orig, ver), src = self._ctx_cache[0], self._ctx_cache[2]
+            if (orig is ctx and ver == ctx._version) or (src.shape == ctx.shape and src.dtype == ctx.dtype
+                                                         and src.device == ctx.device and torch.equal(src, ctx)):
+                return self._ctx_cache[1]
+        key = (ctx, ctx._version)
         bc, tk, cd = ctx.shape
         c16 = ctx.detach().to(device=self.device, dtype=F16).contiguous()
         ldv = (tk + 7) & ~7
@@ -371,7 +376,7 @@ class NetEngine:
                 ops.igemm(c16, blk["kv2_w"], 2 * c, batch=bc, hin=1, win=tk, hout=1, wout=tk, c0=cd, out=k, ld_out=c,
                           out_t=vt, n_tr_begin=c, ld_t=ldv, ws=self._ws())
                 kvs.append((k, vt, bc, tk, ldv))
-        self._ctx_cache = (key, kvs, ctx)
+        self._ctx_cache = (key, kvs, ctx.detach().clone())
         return kvs
 
     def _all_st(self):
@@ -383,9 +388,12 @@ class NetEngine:
     def hint_features(self, hint):
         """input_hint_block (cldm.py:599-615): 8 convs with SiLU between; t-independent, cached per hint tensor.
         hint: NCHW fp32 [B,3,8h,8w] in [0,1].  Returns a persistent Act [B, h*w, model_channels]."""
-        key = (hint.data_ptr(), hint._version, tuple(hint.shape))
-        if self._hint_cache is not None and self._hint_cache[0] == key:
-            return self._hint_cache[1]
+        if self._hint_cache is not None:   # content-keyed, against the retained ORIGINAL tensor (see context_kv)
+            (o, ver), src = self._hint_cache[0], self._hint_cache[2]
+            if (o is hint and ver == hint._version) or (src.shape == hint.shape and src.dtype == hint.dtype
+                                                        and src.device == hint.device and torch.equal(src, hint)):
+                return self._hint_cache[1]
+        key, orig = (hint, hint._version), hint
         b, c, hh, ww = hint.shape
         hint = hint.detach().to(device=self.device, dtype=F32).contiguous()
         x = torch.empty((b, hh * ww, 8), dtype=F16, device=self.device)
@@ -397,7 +405,7 @@ class NetEngine:
             out = torch.empty((b, ho * wo, hc["cout"]), dtype=F16, device=self.device)
             a = self.conv(a, hc["w"], hc["cout"], k=3, stride=hc["stride"], bias=hc["b"],
                           act=MD_ACT_NONE if last else MD_ACT_SILU, out=out)
-        self._hint_cache = (key, a, hint)
+        self._hint_cache = (key, a, orig.detach().clone())
         return a
 
     # ------------------------------------------------------------------ blocks

@@ -122,15 +122,18 @@ def gemv_f32(x, w, bias, y, rows, k, n, act_in=False):
     return y
 
 
-def select_row_f32(table, counter, row_offset, dst, width):
-    _lib.check(_lib.load().md_select_row_f32(_p(table), _p(counter), row_offset, _p(dst), width, stream_ptr()),
+def select_row_f32(table, counter, row_offset, dst, width, nrows=None):
+    nrows = int(table.numel() // width) if nrows is None else nrows
+    _lib.check(_lib.load().md_select_row_f32(_p(table), _p(counter), row_offset, nrows, _p(dst), width, stream_ptr()),
                "md_select_row_f32")
     return dst
 
 
-def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst):
-    _lib.check(_lib.load().md_gather_rows(_p(table), _p(seg), nseg, max_row_units, _p(counter), row_offset, _p(dst),
-                                          stream_ptr()), "md_gather_rows")
+def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst, nrows, rows_per_block=None, block_units=0):
+    """rows_per_block None: the whole table is one block (row r of segment s at seg_off_s + r * len_s)."""
+    rows_per_block = nrows if rows_per_block is None else rows_per_block
+    _lib.check(_lib.load().md_gather_rows(_p(table), _p(seg), nseg, max_row_units, _p(counter), row_offset, nrows,
+                                          rows_per_block, block_units, _p(dst), stream_ptr()), "md_gather_rows")
     return dst
 
 
@@ -155,6 +158,12 @@ class Graph:
 
     def end(self):
         _lib.check(_lib.load().md_graph_end(stream_ptr(), C.byref(self.handle)), "md_graph_end")
+
+    def abort(self):
+        """end a capture that failed half-way and drop whatever was recorded (never raises)"""
+        h = C.c_void_p(0)
+        if _lib.load().md_graph_end(stream_ptr(), C.byref(h)) == 0 and h:
+            _lib.load().md_graph_destroy(h)
 
     def launch(self):
         _lib.check(_lib.load().md_graph_launch(self.handle, stream_ptr()), "md_graph_launch")

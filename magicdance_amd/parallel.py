@@ -5,13 +5,14 @@ dataset/tiktok_video_arnold_copy.py:128-131).
 Frames are independent given (pose_f, x_T, reference latent, text context, weights), so rank r owns a contiguous
 block of frames and runs them as one batch.  The only shared quantity is the appearance bank: with ``wonoise`` it
 depends on (reference latent, t, ctx) only, i.e. on the DDIM step but not on the frame.  The S banks are therefore
-computed once per sequence: rank r runs the appearance net for a contiguous block of S/world steps (batched over those
-timesteps) and applies the UNet's to_k / to_v to them -- the "reference-image KV" of the north star, 46 MB fp16 per
-step at 512x512 -- and the equal row blocks are exchanged with one RCCL all-gather per table segment (point-to-point xGMI
-links: every link carries a different block at the same time).  After that the 50-step loop has no collective at all:
-every rank replays its captured step graph (pose ControlNet + UNet cond/uncond + CFG/DDIM update) reading table row
-``step``.  Final latents are all-gathered (the decoded-frame gather of the north star, at the latent seam of this
-round's scope).
+computed once per sequence: the table is laid out [row block][segment] (ddim.FusedStepRunner._allocate_table); per chunk
+of ``world`` blocks, rank r runs the appearance net for ITS block of timesteps (one batched pass) and applies the UNet's
+to_k / to_v -- the "reference-image KV" of the north star, 46 MB fp16 per step at 512x512 -- and ONE in-place RCCL all-gather
+exchanges the chunk's contiguous blocks (point-to-point xGMI links: every link carries a different block at the same time).
+The table is split into two chunks so that the second all-gather overlaps the first steps of the loop.  The 50-step loop
+itself has no collective: every rank replays its captured step graph (pose ControlNet + UNet cond/uncond + CFG/DDIM
+update) reading table row ``step``.  Decoded frames (or latents) are all-gathered at the end.  Every rank issues the same
+collectives in the same order whatever its own number of frames (uneven and empty shards included).
 """
 import torch
 
@@ -22,6 +23,13 @@ class FrameShardedSampler:
     def __init__(self, model, rank=0, world=1, group=None):
         self.model, self.rank, self.world, self.group = model, rank, world, group
 
+    @staticmethod
+    def frame_block(F, rank, world):
+        """Contiguous frame block [f0, f1) of ``rank``: sizes differ by at most one frame, earlier ranks take the extra ones."""
+        q, r = divmod(F, world)
+        f0 = rank * q + min(rank, r)
+        return f0, f0 + q + (1 if rank < r else 0)
+
     def _cond(self, pose, ctx, ref):
         b = pose.shape[0]
         rep = lambda t: t if t.shape[0] == b else t.expand(b, *t.shape[1:])  # noqa: E731
@@ -30,36 +38,32 @@ class FrameShardedSampler:
         uc = {"c_concat": [pose], "c_crossattn": [rep(ctx)], "wonoise": True, "overlap_sampling": False}
         return c, uc
 
-    def table_rows(self, S):
-        """Rows per table segment: S padded to a multiple of the world size (equal blocks -> one all-gather per segment)."""
-        return -(-S // self.world) * self.world
+    def _runner(self):
+        st = self.model._fused
+        if st is None:
+            st = self.model._fused = FusedStepRunner(self.model)
+        return st
 
-    def row_block(self, S, rank):
-        """DDIM rows [r0, r1) whose reference-KV this rank computes: the valid part of its equal block of the padded table."""
-        q = self.table_rows(S) // self.world
-        return min(S, rank * q), min(S, (rank + 1) * q)
-
-    def _fill_table(self, st):
-        """Reference-KV table of the whole schedule: every rank runs the appearance net (batched over its block of
-        timesteps) for ~S/world rows, then ONE RCCL all-gather per table segment (K or V^T of a bank entry, 32 segments)
-        exchanges the equal row blocks -- every xGMI link carries a different block at the same time, instead of world x 32
-        root->peers broadcasts one after the other."""
-        r0, r1 = self.row_block(st.S, self.rank)
-        if r1 > r0:
-            st.compute_bank_rows(range(r0, r1))
-        if self.world > 1:
-            import torch.distributed as dist
-            q = st.table_rows // self.world
-            per_rank = [st.table_slabs(src * q, (src + 1) * q) for src in range(self.world)]   # [rank][segment] views
-            for seg in range(len(per_rank[0])):
-                outs = [per_rank[src][seg] for src in range(self.world)]
-                dist.all_gather(outs, outs[self.rank].clone(), group=self.group)
+    def _gather(self, z, counts=None):
+        """all-gather of per-rank results along the frame axis; ``counts`` (frames per rank) when the shards are uneven: the
+        shards are padded to the largest one for the collective and trimmed afterwards."""
+        import torch.distributed as dist
+        if counts is None:
+            outs = [torch.empty_like(z) for _ in range(self.world)]
+            dist.all_gather(outs, z, group=self.group)
+            return torch.cat(outs, 0)
+        m = max(counts)
+        pad = torch.zeros((m,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+        pad[:z.shape[0]] = z
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(outs, pad, group=self.group)
+        return torch.cat([o[:n] for o, n in zip(outs, counts)], 0)
 
     @torch.no_grad()
     def sample(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, gather=True, decode=False):
         """pose [Bl,3,8h,8w] = this rank's frames; ctx [1,77,768]; ref [1,4,h,w]; x_T [Bl,4,h,w].
         Returns the latents -- or, with ``decode``, the first-stage-decoded frames [.,3,8h,8w] -- of ALL frames
-        (rank order) when ``gather`` else this rank's."""
+        (rank order) when ``gather`` else this rank's.  Equal frame counts per rank (use sample_sequence otherwise)."""
         model = self.model
         c, uc = self._cond(pose, ctx, ref)
         if self.world == 1:
@@ -67,64 +71,128 @@ class FrameShardedSampler:
                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc, inpaint=None,
                                     x_T=x_T)
             return model.decode_first_stage(z) if decode else z
-        import torch.distributed as dist
         sampler = DDIMSampler_ReferenceOnly(model)
         sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
-        st = model._fused
-        if st is None:
-            st = model._fused = FusedStepRunner(model)
+        st = self._runner()
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            st.prepare(c, x_T, sampler, scale, table_mode=True, table_rows=self.table_rows(ddim_steps))
-            S = st.S
-            self._fill_table(st)
-            for _ in range(S):
-                st.step()
+            st.prepare(c, x_T, sampler, scale, table_mode=True, world=self.world)
+            st.run_steps(self.rank, self.world, self.group)
             z = st.x.clone()
             if decode:
                 z = model.decode_first_stage(z)
             if gather:   # the all-gather of decoded frames of the north star (latents when the caller decodes itself)
-                outs = [torch.empty_like(z) for _ in range(self.world)]
-                dist.all_gather(outs, z, group=self.group)
-                z = torch.cat(outs, 0)
+                z = self._gather(z)
         caller.wait_stream(st.stream)
         return z
 
     @torch.no_grad()
-    def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0, decode=False):
+    def sample_sequence(self, pose_frames, ctx, ref, x_T, frames_per_batch=8, ddim_steps=50, scale=7.0, decode=False,
+                        gather_counts=None):
         """A whole pose sequence sharing one reference image (the entry points' use case, test_any_image_pose.py:201-262:
         same ref latent, same text, same x_T for every frame).  With ``wonoise`` the appearance bank depends on the DDIM
-        step only, so the S banks are computed ONCE per sequence (equal row blocks per rank + RCCL all-gathers when world > 1)
-        and every batch of ``frames_per_batch`` frames replays the captured step graph in table mode.
-        pose_frames [F,3,8h,8w] = this rank's frames; x_T [1,4,h,w].  Returns this rank's latents [F,4,h,w]."""
+        step only, so the reference-KV table is filled ONCE per sequence -- by the first batch's run, overlapped with its steps;
+        every rank takes part in every chunk's all-gather exactly once, whatever its number of frames (a rank with no frames
+        fills its blocks and steps nothing) -- and the remaining batches of ``frames_per_batch`` frames only replay the captured
+        step graph.  pose_frames [F,3,8h,8w] = this rank's frames (F may be 0 and may differ between ranks); x_T [1,4,h,w].
+        Returns this rank's latents / decoded frames [F,...], or those of all ranks when ``gather_counts`` (frames per rank)."""
         model = self.model
         sampler = DDIMSampler_ReferenceOnly(model)
         sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
-        st = model._fused
-        if st is None:
-            st = model._fused = FusedStepRunner(model)
+        st = self._runner()
         F = pose_frames.shape[0]
         outs = []
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            have_table = False
+            if F == 0:   # empty shard: fill this rank's table blocks (collectives included), no steps
+                dummy = torch.zeros((1, 3, 8 * x_T.shape[2], 8 * x_T.shape[3]), dtype=x_T.dtype, device=x_T.device)
+                c, _ = self._cond(dummy, ctx, ref)
+                st.prepare(c, x_T[:1].contiguous(), sampler, scale, table_mode=True, world=self.world)
+                st.run_steps(self.rank, self.world, self.group, steps=False)
             for f0 in range(0, F, frames_per_batch):
                 pose = pose_frames[f0:f0 + frames_per_batch].contiguous()
                 b = pose.shape[0]
                 c, _ = self._cond(pose, ctx, ref)
-                old_key = st.key
-                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True,
-                           table_rows=self.table_rows(ddim_steps))
-                if not have_table or st.key != old_key:   # (re)allocated buffers: the table must be filled for this geometry
-                    self._fill_table(st)
-                    have_table = True
-                for _ in range(st.S):
-                    st.step()
+                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True, world=self.world)
+                st.run_steps(self.rank, self.world, self.group, fill=(f0 == 0))
                 outs.append(model.decode_first_stage(st.x) if decode else st.x.clone())
+            if outs:
+                z = torch.cat(outs, 0)
+            else:
+                side = 8 * x_T.shape[2] if decode else x_T.shape[2]
+                z = torch.zeros((0, 3 if decode else x_T.shape[1], side, side), dtype=torch.float32, device=x_T.device)
+            if gather_counts is not None and self.world > 1:
+                z = self._gather(z, list(gather_counts))
         caller.wait_stream(st.stream)
-        return torch.cat(outs, 0)
+        return z
+
+    @torch.no_grad()
+    def network_pass_times(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, reps=5):
+        """Metric (ii) of SURVEY 8(d), "UNet ms/step": HIP-event time of ONE forward of each network at this batch size B =
+        pose.shape[0] -- ``unet_read`` (ControlledUnetModelAttnPose read branch: bank attention + pose residuals), ``unet_uc``
+        (plain branch), ``pose`` (ControlNet incl. its 13 zero-convs), ``appearance`` (ControlNetReferenceOnly write pass, B = 1:
+        the reference image is shared) and ``unet_cfg_2b`` (what a step actually launches: read + uc batched as 2B samples).
+        Each pass is captured into a HIP graph and replayed ``reps`` times between two events on the launch stream."""
+        from . import ops
+        from .engine import Act
+        model = self.model
+        c, _ = self._cond(pose, ctx, ref)
+        sampler = DDIMSampler_ReferenceOnly(model)
+        sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
+        st = self._runner()
+        app, pose_e, unet = model.engines()
+        b = pose.shape[0]
+        out = {}
+        with torch.cuda.stream(st.stream):
+            st.prepare(c, x_T, sampler, scale, table_mode=True)
+            st.compute_bank_rows(range(min(st.S, st.per)))
+            st.counter.zero_()
+            ops.select_row_f32(st.ts_table, st.counter, 0, st.t_cur, 2 * b, st.S)
+            ops.gather_rows(st.bank_table, st.bank_seg, st.bank_seg.shape[0], st.bank_seg_max, st.counter, 0, st.bank_cur,
+                            st.S, st.per, st.block_elems // 8)
+            unet.arena.reset()
+            pres = [Act(p.t.clone(), p.b, p.h, p.w, p.c) for p in pose_e.pose(st.x, st.hint_feat, st.t_cur[:b], st.kv_pose)]
+            bref = st.ref.shape[0]
+            passes = {
+                "unet_read": lambda: unet.unet(st.x, st.t_cur[:b], st.kv_unet_uc, banks=st.bank_cur_kv, pose=pres, nread=b,
+                                               only_mid_control=model.only_mid_control),
+                "unet_uc": lambda: unet.unet(st.x, st.t_cur[:b], st.kv_unet_uc, nread=0),
+                "unet_cfg_2b": lambda: unet.unet([st.x, st.x], st.t_cur, st.kv_unet, banks=st.bank_cur_kv, pose=pres, nread=b,
+                                                 only_mid_control=model.only_mid_control),
+                "pose": lambda: pose_e.pose(st.x, st.hint_feat, st.t_cur[:b], st.kv_pose),
+                "appearance": lambda: app.appearance(st.ref, st.t_cur[:bref], st.kv_app),
+            }
+            for name, fn in passes.items():
+                def run():
+                    unet.arena.reset()
+                    fn()
+                run()                                   # warm: sizes the arena (allocation is illegal under capture)
+                st.stream.synchronize()
+                g = ops.Graph()
+                unet.arena.frozen = True
+                try:
+                    g.begin()
+                    try:
+                        run()
+                    except BaseException:
+                        g.abort()
+                        raise
+                    g.end()
+                finally:
+                    unet.arena.frozen = False
+                g.launch()
+                st.stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st.stream)
+                for _ in range(reps):
+                    g.launch()
+                e1.record(st.stream)
+                st.stream.synchronize()
+                g.destroy()
+                out[name] = e0.elapsed_time(e1) / reps
+        return out
 
     @torch.no_grad()
     def profile_one_step(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, decode=False):

@@ -282,7 +282,14 @@ def q_sample(ac, x0, t, noise):
     return a * x0 + b * noise
 
 
-def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record=None, stage1=False):
+def overlap_windows(num_frames, offset, window=16, stride=12):
+    """ddim.py:576-577: frame-index windows of the temporal overlap sampling, ``indices = arange(start, start + 16) % F`` for
+    ``start in range(offset, offset + F - 16 + 1 + 12, 12)``."""
+    return [torch.arange(s0, s0 + window) % num_frames for s0 in range(offset, offset + num_frames - window + 1 + stride, stride)]
+
+
+def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record=None, stage1=False, q_noises=None,
+                offsets=None):
     """ddim.py:391-516 + 519-645 ('controlnet is more important' branch :595-605, or the 'balance' 2B-batched branch
     :540-567 when the unconditional dict carries ``image_control`` too; eps parameterisation,
     eta = 0 so sigma_t = 0 and the noise term vanishes; the reference still draws it, :641).
@@ -297,7 +304,10 @@ def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record
     for i, step in enumerate(np.flip(ts)):
         index = len(ts) - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
-        ref = ref0 if cond["wonoise"] else q_sample(ac, ref0, t, torch.randn_like(ref0))   # :529-535
+        if cond["wonoise"]:
+            ref = ref0
+        else:   # :529-535; ``q_noises[i]`` = the randn_like draw of step i (fixtures record it), else drawn here
+            ref = q_sample(ac, ref0, t, torch.randn_like(ref0) if q_noises is None else q_noises[i])
         if uncond is None or scale == 1.0:
             e_t = apply_model(sd, cfg, img, t, cond, ref, stage1=stage1)                    # :537-538
             e_c = e_u = e_t
@@ -307,6 +317,22 @@ def ddim_sample(sd, cfg, cond, uncond, x_T, steps=50, eta=0.0, scale=7.0, record
             e_u, e_c = apply_model(sd, cfg, torch.cat([img] * 2), torch.cat([t] * 2), c_in, torch.cat([ref] * 2),
                                    stage1=stage1).chunk(2)
             e_t = e_u + scale * (e_c - e_u)
+        elif cond.get("overlap_sampling"):                                                  # :569-594
+            # windows of 16 frames, stride 12, from a random offset (python ``random``, :575 -- passed in as offsets[i]);
+            # per-window CFG, accumulated and divided by the per-frame visit count
+            nf = cond["c_concat"][0].shape[0]
+            import random
+            off = random.randint(0, nf - 1) if offsets is None else int(offsets[i])
+            pred_all, counts = torch.zeros_like(img), torch.zeros(nf)
+            for idx in overlap_windows(nf, off):
+                c_w = dict(cond)
+                c_w["c_concat"] = [cond["c_concat"][0][idx]]
+                m_t = apply_model(sd, cfg, img[idx], t, c_w, ref, stage1=stage1)
+                m_u = apply_model(sd, cfg, img[idx], t, c_w, None, uc=True, stage1=stage1)
+                pred_all[idx] += m_u + scale * (m_t - m_u)
+                counts[idx] += 1
+            e_t = pred_all / counts.reshape(-1, 1, 1, 1)
+            e_c = e_u = e_t
         else:
             e_c = apply_model(sd, cfg, img, t, cond, ref, stage1=stage1)                    # :603
             e_u = apply_model(sd, cfg, img, t, cond, None, uc=True, stage1=stage1)          # :604

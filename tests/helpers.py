@@ -57,6 +57,20 @@ def case_inputs(g):
     return dict(ref=ref, ctx=ctx, x_T=x_T, pose=pose, c=c, uc=uc, uc_balance=uc_balance)
 
 
+def overlap_case_inputs(g):
+    """Inputs of the overlap_sampling fixture (oracle/make_golden.py 'overlap'): 16 pose frames, one reference / text repeated per
+    frame, per-frame x_T as stored."""
+    side, frames = int(g["side"]), int(g["frames"])
+    inp = synthetic.synth_inputs((side, side), frames=frames, seed=int(g["seed"]))
+    rep = lambda x: x.repeat(frames, *([1] * (x.dim() - 1)))
+    ref, ctx, pose = rep(inp["ref"]), rep(inp["ctx"]), inp["pose"]
+    x_T = torch.from_numpy(g["x_T"])
+    assert np.array_equal(inp["ref"].numpy(), g["ref"]) and x_T.shape[0] == frames
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": True}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": True}
+    return dict(ref=ref, ctx=ctx, x_T=x_T, pose=pose, c=c, uc=uc)
+
+
 def summarize(t):
     flat = t.detach().float().reshape(-1)
     return np.array([flat.mean().item(), flat.std().item(), flat.abs().max().item(), flat.norm().item()], np.float64)

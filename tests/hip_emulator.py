@@ -157,18 +157,22 @@ def softmax_rows(s, ld_s, p, ld_p, rows, cols, scale):
     return p
 
 
-def select_row_f32(table, counter, row_offset, dst, width):
-    row = (int(counter[0]) if counter is not None else 0) + row_offset
+def select_row_f32(table, counter, row_offset, dst, width, nrows=None):
+    nrows = int(table.numel() // width) if nrows is None else nrows
+    row = min(max((int(counter[0]) if counter is not None else 0) + row_offset, 0), nrows - 1)
     _mem(dst, (width,), (1,)).copy_(_mem(table, (row + 1, width), (width, 1))[row])
     return dst
 
 
-def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst):
-    row = (int(counter[0]) if counter is not None else 0) + row_offset
+def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst, nrows, rows_per_block=None, block_units=0):
+    rows_per_block = nrows if rows_per_block is None else rows_per_block
+    row = min(max((int(counter[0]) if counter is not None else 0) + row_offset, 0), nrows - 1)
+    blk, within = divmod(row, rows_per_block)
     tab, d = table.view(-1), dst.view(-1)
     u = 16 // tab.element_size()
     for off, ln, doff in seg.view(-1, 3).tolist()[:nseg]:
-        d[doff * u:(doff + ln) * u].copy_(tab[(off + row * ln) * u:(off + (row + 1) * ln) * u])
+        src = blk * block_units + off + within * ln
+        d[doff * u:(doff + ln) * u].copy_(tab[src * u:(src + ln) * u])
     return dst
 
 
@@ -200,6 +204,9 @@ class Graph:
         self.fn = None
 
     def end(self):
+        pass
+
+    def abort(self):
         pass
 
     def launch(self):

@@ -190,3 +190,41 @@ def test_repeated_sampling_is_bit_identical(dev):
         outs.append(z.clone())
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_wonoise_false_matches_reference_golden(dev):
+    """wonoise=False (ddim.py:529-535 + ddpm.py:356-359) on the generic per-step route; the per-step q_sample draws
+    come from the fixture (tests/test_host_logic.py::noisy_q_sample), everything else runs on the HIP kernels."""
+    from tests.test_host_logic import noisy_q_sample
+    g = H.load_golden("small_b1_noisy")
+    model = _model(g, dev)
+    inp = H.case_inputs(g)
+    c, uc = _to_dev(dict(inp["c"], wonoise=False), dev), _to_dev(dict(inp["uc"], wonoise=False), dev)
+    model._fused = None
+    model.q_sample = noisy_q_sample(model, torch.from_numpy(g["q_noises"]))
+    try:
+        traj = []
+        z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
+                                unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"].to(dev),
+                                img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
+    finally:
+        del model.q_sample
+    assert model._fused is None
+    assert _rel(z.cpu().numpy(), g["z"], "small_b1_noisy z vs golden") <= TOL_Z
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b1_noisy pred_x0 trajectory vs golden") <= TOL_Z
+
+
+def test_overlap_sampling_matches_reference_golden(dev):
+    """overlap_sampling (ddim.py:569-594): 16-frame windows / stride 12 from python-random offsets, generic route."""
+    import random
+    g = H.load_golden("small_b16_overlap")
+    model = _model(g, dev)
+    inp = H.overlap_case_inputs(g)
+    c, uc = _to_dev(inp["c"], dev), _to_dev(inp["uc"], dev)
+    random.seed(int(g["random_seed"]))
+    traj = []
+    z, _ = model.sample_log(cond=c, batch_size=int(g["frames"]), ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                            unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"].to(dev),
+                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
+    assert _rel(z.cpu().numpy(), g["z"], "small_b16_overlap z vs golden") <= TOL_Z
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b16_overlap pred_x0 trajectory vs golden") <= TOL_Z

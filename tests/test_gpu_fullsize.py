@@ -36,8 +36,9 @@ def model(dev):
     m = H.build_hip_model(320, 8, seed=0, device=dev, image_size=64)
     yield m
     os.makedirs(os.path.join(H.ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(H.ROOT, "gpurun_out", "parity_fullsize.log"), "a") as f:
-        f.write("\n".join(_LOG) + "\n")
+    tag = "" if os.environ.get("MD_RES_LO", "1") != "0" else "_single_term_stream"
+    with open(os.path.join(H.ROOT, "gpurun_out", f"parity_fullsize{tag}.log"), "a") as f:
+        f.write(f"# MD_RES_LO={os.environ.get('MD_RES_LO', '1')} (1 = two-term fp16 residual stream)\n" + "\n".join(_LOG) + "\n")
 
 
 def _rel(a, b):

@@ -347,7 +347,8 @@ def test_graph_and_profile(dev):
 
 
 def test_gather_rows(dev):
-    """md_gather_rows: multi-segment row pick of the reference-KV table (bit-exact copy, device-side row counter)."""
+    """md_gather_rows: multi-segment row pick of the reference-KV table (bit-exact copy, device-side row counter clamped to
+    the table), single-block and blocked ([row block][segment][rows per block][len]) layouts."""
     from magicdance_amd import ops
     g = torch.Generator().manual_seed(0)
     S, lens = 5, [8 * 3, 8 * 1000, 8 * 17]          # fp16 elements per row, per segment (16-byte multiples)
@@ -361,12 +362,39 @@ def test_gather_rows(dev):
     seg = torch.tensor(segs, dtype=torch.int64, device=dev)
     dst = torch.zeros(doff, dtype=F16, device=dev)
     counter = torch.tensor([3], dtype=torch.int32, device=dev)
-    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), counter, 0, dst)
+    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), counter, 0, dst, S)
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu(), torch.cat([t[3] for t in tabs]))
-    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), None, 1, dst)
+    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), None, 1, dst, S)
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu(), torch.cat([t[1] for t in tabs]))
+    ops.gather_rows(table, seg, len(segs), max(s[1] for s in segs), counter, 9, dst, S)   # 3 + 9 -> clamped to the last row
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), torch.cat([t[S - 1] for t in tabs]))
+    # blocked: 3 blocks of 2 rows (6 rows, the last one padding), block = [segment][2][len]
+    per, nblk = 2, 3
+    tabs6 = [torch.cat([t, torch.zeros(1, t.shape[1], dtype=t.dtype)]) for t in tabs]
+    blocks = [torch.cat([t[b * per:(b + 1) * per].reshape(-1) for t in tabs6]) for b in range(nblk)]
+    block_elems = blocks[0].numel()
+    tableb = torch.cat(blocks).to(dev)
+    segs, boff, doff = [], 0, 0
+    for ln in lens:
+        segs.append((boff // 8, ln // 8, doff // 8))
+        boff += per * ln
+        doff += ln
+    segb = torch.tensor(segs, dtype=torch.int64, device=dev)
+    for row in range(S):
+        counter.fill_(row)
+        ops.gather_rows(tableb, segb, len(segs), max(s[1] for s in segs), counter, 0, dst, S, per, block_elems // 8)
+        torch.cuda.synchronize()
+        assert torch.equal(dst.cpu(), torch.cat([t[row] for t in tabs])), row
+    # select_row clamps too
+    tbl = torch.arange(12, dtype=F32, device=dev).reshape(4, 3)
+    d3 = torch.zeros(3, dtype=F32, device=dev)
+    counter.fill_(7)
+    ops.select_row_f32(tbl, counter, 0, d3, 3)
+    torch.cuda.synchronize()
+    assert d3.tolist() == [9.0, 10.0, 11.0]
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 320, 960), (1, 64, 1280, 1280), (2, 1000, 640, 640), (1, 77, 64, 128)])

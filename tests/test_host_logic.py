@@ -182,3 +182,62 @@ def test_clip_embedder_wrapper_behaviour():
     assert tuple(emb(["x"]).shape) == (1, 1, 64)
     emb.layer, emb.layer_idx = "hidden", -2
     assert tuple(emb(["x"]).shape) == (1, 77, 64)
+
+
+def _no_graph(monkeypatch):
+    from magicdance_amd import ddim
+    orig_init = ddim.FusedStepRunner.__init__
+
+    def init(self, model):
+        orig_init(self, model)
+        self.use_graph = False
+    monkeypatch.setattr(ddim.FusedStepRunner, "__init__", init)
+
+
+def noisy_q_sample(model, noises):
+    """q_sample hook for the wonoise=False fixtures: same arithmetic (cldm.q_sample, ddpm.py:356-359), but the per-step
+    randn_like draw is taken from the fixture (the reference's CPU generator stream cannot be reproduced on another device)."""
+    it = iter(noises)
+    orig = type(model).q_sample
+    return lambda x_start, t, noise=None: orig(model, x_start, t, noise=next(it).to(x_start.device) if noise is None else noise)
+
+
+def test_wonoise_false_route_matches_reference_golden(monkeypatch):
+    """wonoise=False re-noises the reference latent with q_sample every step (ddim.py:529-535); generic route."""
+    hip_emulator.install(monkeypatch)
+    g = H.load_golden("small_b1_noisy")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
+                              image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    c, uc = dict(inp["c"], wonoise=False), dict(inp["uc"], wonoise=False)
+    monkeypatch.setattr(model, "q_sample", noisy_q_sample(model, torch.from_numpy(g["q_noises"])), raising=False)
+    traj = []
+    z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
+                            unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"],
+                            img_callback=lambda p0, i: traj.append(p0.clone()))
+    assert model._fused is None, "wonoise=False must not take the reference-KV table route (the bank depends on the noise)"
+    assert _rel(z.numpy(), g["z"]) <= 2e-2
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"]) <= 2e-2
+    # the q_sample arithmetic itself
+    x0, n = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    t = torch.tensor([10, 900])
+    ac = model.alphas_cumprod
+    want = ac[t].sqrt()[:, None, None, None] * x0 + (1 - ac[t]).sqrt()[:, None, None, None] * n
+    assert torch.allclose(type(model).q_sample(model, x0, t, noise=n), want, atol=1e-6)
+
+
+def test_overlap_sampling_route_matches_reference_golden(monkeypatch):
+    """overlap_sampling temporal windows (ddim.py:569-594), generic route, python-random offsets seeded as in the fixture."""
+    import random
+    hip_emulator.install(monkeypatch)
+    g = H.load_golden("small_b16_overlap")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
+                              image_size=int(g["side"]))
+    inp = H.overlap_case_inputs(g)
+    random.seed(int(g["random_seed"]))
+    traj = []
+    z, _ = model.sample_log(cond=inp["c"], batch_size=int(g["frames"]), ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                            unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"],
+                            img_callback=lambda p0, i: traj.append(p0.clone()))
+    assert _rel(z.numpy(), g["z"]) <= 2e-2
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"]) <= 2e-2

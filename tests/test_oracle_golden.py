@@ -83,3 +83,40 @@ def test_stage1_container_has_the_reference_state_dict_layout():
     mine = H.synth_weights(int(g["geo_model_channels"]), int(g["geo_num_heads"]), stage1=True)
     want = dict(line.rsplit(":", 1) for line in str(g["state_keys"]).split("\n"))
     assert {k: str(tuple(v.shape)) for k, v in mine.items()} == want
+
+
+def test_restatement_wonoise_false_matches_reference_golden():
+    """wonoise=False (ddim.py:529-535): the reference latent is re-noised with q_sample (ddpm.py:356-359) at every step; the
+    fixture records the reference's own randn_like draws."""
+    g = H.load_golden("small_b1_noisy")
+    mc, nh = int(g["geo_model_channels"]), int(g["geo_num_heads"])
+    sd = H.synth_weights(mc, nh, seed=int(g["seed"]))
+    inp = H.case_inputs(g)
+    c, uc = dict(inp["c"], wonoise=False), dict(inp["uc"], wonoise=False)
+    traj = []
+    with torch.no_grad():
+        z = R.ddim_sample(sd, R.Cfg(model_channels=mc, num_heads=nh), c, uc, inp["x_T"], steps=int(g["steps"]), eta=0.0,
+                          scale=7.0, record=lambda i, d: traj.append(d["pred_x0"]), q_noises=torch.from_numpy(g["q_noises"]))
+    scale = float(np.abs(g["z"]).max())
+    assert float(np.abs(z.numpy() - g["z"]).max()) <= 2e-5 * max(1.0, scale)
+    np.testing.assert_allclose(torch.stack(traj).numpy(), g["pred_x0_traj"], atol=2e-5 * max(1.0, scale), rtol=1e-4)
+
+
+def test_restatement_overlap_sampling_matches_reference_golden():
+    """overlap_sampling (ddim.py:569-594): 16-frame windows, stride 12, from python-``random`` offsets (seeded as the fixture
+    records), per-window CFG, averaged by visit count."""
+    import random
+    g = H.load_golden("small_b16_overlap")
+    mc, nh, frames = int(g["geo_model_channels"]), int(g["geo_num_heads"]), int(g["frames"])
+    assert [w.tolist() for w in R.overlap_windows(16, 5)] == [[(5 + j) % 16 for j in range(16)], [(17 + j) % 16 for j in range(16)]]
+    assert len(R.overlap_windows(20, 0)) == 2 and R.overlap_windows(20, 0)[1][:3].tolist() == [12, 13, 14]
+    sd = H.synth_weights(mc, nh, seed=int(g["seed"]))
+    inp = H.overlap_case_inputs(g)
+    random.seed(int(g["random_seed"]))
+    traj = []
+    with torch.no_grad():
+        z = R.ddim_sample(sd, R.Cfg(model_channels=mc, num_heads=nh), inp["c"], inp["uc"], inp["x_T"], steps=int(g["steps"]),
+                          eta=0.0, scale=7.0, record=lambda i, d: traj.append(d["pred_x0"]))
+    scale = float(np.abs(g["z"]).max())
+    assert z.shape[0] == frames and float(np.abs(z.numpy() - g["z"]).max()) <= 2e-5 * max(1.0, scale)
+    np.testing.assert_allclose(torch.stack(traj).numpy(), g["pred_x0_traj"], atol=2e-5 * max(1.0, scale), rtol=1e-4)

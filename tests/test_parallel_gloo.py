@@ -1,6 +1,8 @@
-"""CPU tier, world_size 2 over gloo: the frame-sharded sampler (bank table computed round-robin over ranks, broadcast,
-per-rank step loop, latent all-gather) must reproduce the single-process result.  Kernels are emulated on CPU
-(tests/hip_emulator.py); what is under test is the sharding / collective logic of magicdance_amd/parallel.py."""
+"""CPU tier, gloo, world_size 2 / 3 / 4: the frame-sharded sampler (reference-KV table computed block-wise by the ranks and
+exchanged with one in-place all-gather per chunk, per-rank step loop, result all-gather) must reproduce the single-process
+result -- with equal shards (sample), with uneven shards and with EMPTY shards (sample_sequence: every rank must still issue the
+same collectives).  Kernels are emulated on CPU (tests/hip_emulator.py); what is under test is the sharding / collective logic
+of magicdance_amd/parallel.py and the chunk pipeline of magicdance_amd/ddim.py::FusedStepRunner."""
 import os
 import socket
 import sys
@@ -20,14 +22,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _setup(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     import torch.distributed as dist
     from _pytest.monkeypatch import MonkeyPatch
-    from tests import helpers as H, hip_emulator
-    from magicdance_amd import ddim, parallel, synthetic
+    from tests import hip_emulator
+    from magicdance_amd import ddim
     mpatch = MonkeyPatch()
     hip_emulator.install(mpatch)
     orig = ddim.FusedStepRunner.__init__
@@ -37,14 +39,23 @@ def _worker(rank, world, port, out_path):
         self.use_graph = False
     mpatch.setattr(ddim.FusedStepRunner, "__init__", init)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, mpatch
+
+
+def _worker(rank, world, port, out_path):
+    dist, mpatch = _setup(rank, world, port)
+    from tests import helpers as H
+    from magicdance_amd import parallel, synthetic
     try:
         model = H.build_hip_model(64, 2, seed=0, device="cpu", image_size=8)
-        fpg, steps = 1, 5   # odd: the table is padded to 6 rows, rank 1 owns rows 3..4 of its block of 3
+        fpg, steps = 1, 5   # 5 rows over 2 ranks x 2 chunks: blocks of 2 rows, 4 blocks, the last one half padding
         inp = synthetic.synth_inputs((8, 8), frames=fpg * world, seed=3)
         x_T = inp["x_T"].repeat(fpg, 1, 1, 1)
         my = slice(rank * fpg, (rank + 1) * fpg)
         sharded = parallel.FrameShardedSampler(model, rank=rank, world=world)
         z_all = sharded.sample(inp["pose"][my].contiguous(), inp["ctx"], inp["ref"], x_T, ddim_steps=steps, scale=7.0)
+        st = model._fused
+        assert (st.per, st.nblocks, st.n_chunks(world)) == (2, 4, 2)
         if rank == 0:
             model._fused = None
             single = parallel.FrameShardedSampler(model, rank=0, world=1)
@@ -64,5 +75,42 @@ def test_frame_sharding_matches_single_process(tmp_path):
     assert r["z_all"].shape == r["z_ref"].shape == (2, 4, 8, 8)
     # same arithmetic per frame (bank via table vs inline, frames batched vs alone); the CPU emulation picks different
     # conv algorithms for different batch sizes, so fp16-storage rounding flips show up (on the GPU the difference is 0)
+    err = float((r["z_all"] - r["z_ref"]).abs().max() / r["z_ref"].abs().max())
+    assert err <= 6e-3, err
+
+
+def _worker_seq(rank, world, port, out_path, frames):
+    dist, mpatch = _setup(rank, world, port)
+    from tests import helpers as H
+    from magicdance_amd import parallel, synthetic
+    try:
+        model = H.build_hip_model(64, 2, seed=0, device="cpu", image_size=8)
+        steps = 4   # 4 rows: world 3 -> blocks of 1 row, 6 blocks (2 padding), 2 chunks; world 4 -> 1-row blocks, 1 chunk
+        inp = synthetic.synth_inputs((8, 8), frames=frames, seed=5)
+        blocks = [parallel.FrameShardedSampler.frame_block(frames, r, world) for r in range(world)]
+        f0, f1 = blocks[rank]
+        sharded = parallel.FrameShardedSampler(model, rank=rank, world=world)
+        z_all = sharded.sample_sequence(inp["pose"][f0:f1].contiguous(), inp["ctx"], inp["ref"], inp["x_T"], frames_per_batch=1,
+                                        ddim_steps=steps, scale=7.0, gather_counts=[b - a for a, b in blocks])
+        if rank == 0:
+            model._fused = None
+            single = parallel.FrameShardedSampler(model, rank=0, world=1)
+            z_ref = single.sample_sequence(inp["pose"], inp["ctx"], inp["ref"], inp["x_T"], frames_per_batch=2, ddim_steps=steps)
+            torch.save({"z_all": z_all, "z_ref": z_ref, "blocks": blocks}, out_path)
+    finally:
+        dist.destroy_process_group()
+        mpatch.undo()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,frames", [(3, 4), (4, 2)])
+def test_uneven_and_empty_shards(tmp_path, world, frames):
+    """F not divisible by the world size (3 ranks, 4 frames: shards 2 / 1 / 1, rank 0 runs two batches but the table is filled
+    once) and fewer frames than ranks (4 ranks, 2 frames: ranks 2 and 3 hold nothing but still join every all-gather)."""
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker_seq, args=(world, _free_port(), out, frames), nprocs=world, join=True)
+    r = torch.load(out)
+    assert sum(b - a for a, b in r["blocks"]) == frames and r["blocks"][0][0] == 0
+    assert r["z_all"].shape == r["z_ref"].shape == (frames, 4, 8, 8)
     err = float((r["z_all"] - r["z_ref"]).abs().max() / r["z_ref"].abs().max())
     assert err <= 6e-3, err

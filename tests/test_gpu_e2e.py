@@ -11,8 +11,9 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-# relative (to max|ref|) tolerances of the fp16 pipeline
-TOL_BANK, TOL_POSE, TOL_EPS, TOL_Z = 1.5e-2, 1.5e-2, 2e-2, 3e-2
+# relative (to max|ref|) tolerances of the fp16 pipeline = 2x the worst value measured on MI355X (round 2,
+# profiles/round2_parity_e2e.txt: banks <= 1.66e-3, pose residuals <= 1.47e-3, eps <= 1.58e-3, latents / pred_x0 <= 2.67e-3)
+TOL_BANK, TOL_POSE, TOL_EPS, TOL_Z = 3.4e-3, 3e-3, 3.2e-3, 5.4e-3
 
 
 @pytest.fixture(scope="module")
@@ -101,7 +102,7 @@ def test_hip_matches_reference_golden(dev, name):
     z2, _ = smp.ddim_sampling(c, tuple(x_T.shape), x_T=x_T, unconditional_guidance_scale=7,
                               unconditional_conditioning=uc, force_generic=True)
     # same kernels, same order of arithmetic per sample: the two routes agree to fp16 rounding of batched-vs-single tiles
-    assert _rel(z2.cpu().numpy(), z.cpu().numpy(), f"{name} generic vs fused route") <= 5e-3
+    assert _rel(z2.cpu().numpy(), z.cpu().numpy(), f"{name} generic vs fused route") <= 3e-3   # measured <= 1.35e-3
     # replay of the captured graph on a second call (same shapes) must reproduce the first result exactly
     z3, _ = model.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
                              unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=x_T)

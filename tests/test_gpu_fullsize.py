@@ -17,9 +17,12 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-# relative tolerances = 2x the values measured on MI355X (profiles/round2_parity_fullsize.txt)
-TOL_EPS = 4e-3          # one apply_model / one guided eps on the reference's x_t
-TOL_TRAJ = {"c0_b1_s20": 4e-2, "c1_b1_s50": 4e-2, "c2_b8_s2": 8e-3}   # final latent of the free-running loop
+# relative tolerances = 2x the values measured on MI355X (profiles/round2_parity_fullsize.txt: eps pair <= 1.27e-3, bank / pose
+# seams <= 4.6e-4, guided eps per step <= 2.47e-3, final latent 7.97e-4 / 8.60e-4 / 1.44e-3)
+TOL_EPS = 2.6e-3        # one apply_model
+TOL_SEAM = 1e-3         # bank / pose tensors (norm and head slice)
+TOL_GUIDED = 5e-3       # guided eps e_u + 7 (e_c - e_u) on the reference's x_t: CFG 7 combines two evaluations
+TOL_TRAJ = {"c0_b1_s20": 1.8e-3, "c1_b1_s50": 1.6e-3, "c2_b8_s2": 3e-3}   # final latent of the free-running loop
 
 _LOG = []
 
@@ -92,7 +95,7 @@ def test_baseline_config_matches_reference(dev, model, name):
             gs = g[f"pose{i}_sum"]
             worst = max(worst, abs(H.summarize(p)[3] - gs[3]) / gs[3], float(np.abs(H.head_slice(p) - g[f"pose{i}_head"]).max()) / gs[2] / 4)
         _LOG.append(f"{name}: worst bank / pose seam (norm and head slice) rel {worst:.3e}")
-        assert worst <= TOL_EPS
+        assert worst <= TOL_SEAM
     # (2) per-step guided eps on the reference's own x_t (single evaluation, no recurrence)
     ts, a, ap = _schedule(steps)
     xt = g["x_traj"]                                           # [steps + 1, frames, 4, 64, 64]
@@ -108,7 +111,7 @@ def test_baseline_config_matches_reference(dev, model, name):
         curve.append(_rel(got, want))
     _LOG.append(f"{name}: guided eps on the reference x_t, per step: " + " ".join(f"{v:.2e}" for v in curve))
     _LOG.append(f"{name}: guided eps per step: max {max(curve):.3e} mean {np.mean(curve):.3e}")
-    assert max(curve) <= 2 * TOL_EPS, max(curve)               # CFG 7 combines two evaluations (|7 e_c - 6 e_u|)
+    assert max(curve) <= TOL_GUIDED, max(curve)
     # (3) free-running trajectory through sample_log (fused HIP-graph route)
     z, inter = model.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
                                 unconditional_conditioning=uc, inpaint=None, x_T=x_T, log_every_t=1)

@@ -10,7 +10,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 F16, F32 = torch.float16, torch.float32
-TOL_DEC, TOL_MOM = 8e-3, 8e-3
+TOL_DEC, TOL_MOM = 4.6e-3, 3.6e-3   # 2x the measured worst (2.30e-3 decode, 1.80e-3 moments: profiles/round2_parity_vae.txt)
 
 
 @pytest.fixture(scope="module")

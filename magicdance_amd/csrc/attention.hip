@@ -495,6 +495,425 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: v2's LDS-DMA tiles and operand layouts, with the tile loop SOFTWARE-PIPELINED inside each wave so that the matrix pipe
+// and the VALU overlap within ONE instruction stream (at 64^2 the grid is ~2 workgroups per CU, so a SIMD holds 1-2 waves and
+// a wave that runs QK^T -> softmax -> PV back to back leaves the matrix pipe idle during its softmax: v2 measured ~25 % MFMA
+// busy).  Per tile t the wave runs two branch-free blocks:
+//   A: S^T(t+1) = K(t+1) Q^T  (MFMA)   interleaved with   P(t) = exp2(S(t) c - m)  -> fp16 (VALU / transcendental)
+//   B: O^T += V^T(t) P^T(t)    (MFMA)   interleaved with   row max of S(t+1), new running max, rescale factor (VALU)
+// i.e. the exponentials of tile t hide under the QK^T of tile t+1 and the max of tile t+1 under the PV of tile t.  K tiles run
+// one tile ahead of V tiles in their own 2-slot rings; one vmcnt(0) + barrier per tile as in v2.
+// Softmax denominator: where D is not a multiple of 16 (d = 40) the last 16-row fragment of O^T has free rows; row D of the V^T
+// tile in LDS is preset to ones (its DMA is skipped), so O^T[D][q] accumulates sum_kv P -- the row sum comes out of the PV MFMAs
+// (summing exactly the fp16 P that the numerator uses) and the per-score v_add disappears; otherwise the sum stays on the VALU.
+template <int D, int QF>
+__global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr int KSTEPS = DK / 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
+  constexpr int KM = CL == 8 ? 1 : 2;
+  constexpr int KJ = 64 * CL / 256;
+  constexpr int VJ = (DF * 16 * 8 + 255) / 256;
+  constexpr int KBYTES = 64 * CL * 16, VBYTES = VJ * 4096;
+  constexpr int BQ = 64 * QF;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr bool ONES = (D % 16) != 0;
+  constexpr int LI = D / 16, LG = (D % 16) / 4, LR = D % 4;   // O^T fragment / lane group / register of row D
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K slot 0, K slot 1, V slot 0, V slot 1
+  char* const Kring = smem;
+  char* const Vring = smem + 2 * KBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qbase = blockIdx.x * BQ + wave * (16 * QF);
+
+  h8 qf[QF][KSTEPS];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int row = qbase + f * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int d = ks * 32 + lg * 8;
+      if (row < g.nq && d < D) v = *reinterpret_cast<const h8*>(g.q + b * g.q_bs + (long long)row * g.ld_q + h * D + d);
+      qf[f][ks] = v;
+    }
+  }
+
+  const int t0 = (g.n0 + 63) >> 6;
+  const int t1 = (g.k1 != nullptr && b < g.n1_batches) ? ((g.n1 + 63) >> 6) : 0;
+  const int ntiles = t0 + t1;
+
+  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.k0 + b * g.k0_bs), 0, g.n0 * g.ld_k0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.vt0 + b * g.vt0_bs), 0, g.heads * D * g.ld_vt0 * 2, 0x00020000);
+  const half_t* k1p = g.k1 ? g.k1 + b * g.k1_bs : g.k0;
+  const half_t* v1p = g.vt1 ? g.vt1 + b * g.vt1_bs : g.vt0;
+  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(k1p), 0, (g.k1 ? g.n1 * g.ld_k1 : 0) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(v1p), 0, (g.vt1 ? g.heads * D * g.ld_vt1 : 0) * 2, 0x00020000);
+  unsigned ko0[KJ], ko1[KJ], vo0[VJ], vo1[VJ];
+  int krow_[KJ], vkv_[VJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const int i = j * 256 + tid;
+    const int r = i / CL, pos = i % CL;
+    const int gr = 4 * ((r >> 3) & 3) + (r & 3);
+    const int sc = (pos - KM * gr) & (CL - 1);
+    const bool ok = sc * 8 < D;
+    krow_[j] = r;
+    ko0[j] = ok ? (unsigned)(r * g.ld_k0 + h * D + sc * 8) * 2u : OOB;
+    ko1[j] = ok ? (unsigned)(r * g.ld_k1 + h * D + sc * 8) * 2u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) {
+    const int i = j * 256 + tid;
+    const int r = i >> 3, pos = i & 7;
+    const int sc = (pos - r) & 7;
+    const bool ok = r < D;
+    vkv_[j] = sc * 8;
+    vo0[j] = ok ? (unsigned)((h * D + r) * g.ld_vt0 + sc * 8) * 2u : OOB;
+    vo1[j] = ok ? (unsigned)((h * D + r) * g.ld_vt1 + sc * 8) * 2u : OOB;
+  }
+
+  // Tile order: the FULL 64-key tiles of segment 0, then those of segment 1 (software-pipelined loop, no masking), then the
+  // partial last tile of either segment (sequential path below) -- softmax does not care about the order of the keys.
+  const int nf0 = g.n0 >> 6, nf1 = t1 ? (g.n1 >> 6) : 0;
+  const int nfull = nf0 + nf1;
+  auto issue_k = [&](bool live, bool s1, int kv0, int slot) {   // dead tiles (past the end of the loop) fetch zeros
+    char* Ks = Kring + slot * KBYTES;
+    const int nseg = live ? (s1 ? g.n1 : g.n0) : 0;
+    if (s1) {
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k1) * 2u;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk1, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + krow_[j] < nseg) ? ko1[j] : OOB, live ? ksoff : 0u, 0, 0);
+    } else {
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k0) * 2u;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk0, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + krow_[j] < nseg) ? ko0[j] : OOB, live ? ksoff : 0u, 0, 0);
+    }
+  };
+  auto issue_v = [&](bool live, bool s1, int kv0, int slot) {
+    char* Vs = Vring + slot * VBYTES;
+    const int nseg = live ? (s1 ? g.n1 : g.n0) : 0;
+    const unsigned vsoff = live ? (unsigned)kv0 * 2u : 0u;
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      if (ONES && (j * 4 + wave) * 8 >= D) continue;   // rows D.. of the tile are preset (ones row + zero rows): never overwritten
+      if (s1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv1, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + vkv_[j] < nseg) ? vo1[j] : OOB, vsoff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv0, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
+                                                 (kv0 + vkv_[j] < nseg) ? vo0[j] : OOB, vsoff, 0, 0);
+    }
+  };
+  auto issue_full_k = [&](int t, int slot) { issue_k(t < nfull, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot); };
+  auto issue_full_v = [&](int t, int slot) { issue_v(t < nfull, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot); };
+
+  if constexpr (ONES) {  // rows D .. DF*16-1 of both V slots: row D = ones, the rest zeros (128 B per row, any chunk order)
+    static_assert(D % 8 == 0, "preset rows start on a DMA instruction boundary (8 rows)");
+    constexpr int NPRE = (DF * 16 - D) * 8;   // 16-byte chunks per slot
+    for (int i = tid; i < 2 * NPRE; i += 256) {
+      const int slot = i / NPRE, c = i - slot * NPRE;
+      const half_t one = (c < 8) ? (half_t)1.0f : (half_t)0.0f;
+      const h8 v = {one, one, one, one, one, one, one, one};
+      *reinterpret_cast<h8*>(Vring + slot * VBYTES + D * 128 + c * 16) = v;
+    }
+  }
+
+  f4 o[DF][QF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i)
+#pragma unroll
+    for (int f = 0; f < QF; ++f) o[i][f] = f4{0.f, 0.f, 0.f, 0.f};
+  float m_cur[QF];
+  [[maybe_unused]] float l_run[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) l_run[f] = 0.f;
+
+  // S^T of one tile: 4 key fragments x QF query fragments
+  auto qk = [&](int slot, f4 (&st)[QF][4]) {
+    const char* Ks = Kring + slot * KBYTES;
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) st[f][kf] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const h8 kfrag = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          st[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfrag, qf[f][ks], st[f][kf], 0, 0, 0);
+      }
+    }
+  };
+  auto mask_tail = [&](int kv0, int nseg, f4 (&st)[QF][4]) {   // partial tile: kv >= segment length -> -inf
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = kv0 + 32 * (kf >> 1) + 8 * lg + 4 * (kf & 1) + r >= nseg;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
+      }
+  };
+  auto row_max = [&](const f4 (&st)[QF][4], float (&mx)[QF]) {   // scaled by c: the running max lives in the exp2 domain
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float v = st[f][0][0];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaxf(v, st[f][kf][r]);
+      v = fmaxf(v, __shfl_xor(v, 16, 64));
+      v = fmaxf(v, __shfl_xor(v, 32, 64));
+      mx[f] = v * g.c;
+    }
+  };
+  auto exp_part = [&](const f4 (&st)[QF][4], h8 (&pf)[QF][2]) {   // P(t) = exp2(S c - m) as fp16 MFMA operands
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      [[maybe_unused]] float ps = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[f][kf][r] * g.c - m_cur[f]);
+          if constexpr (!ONES) ps += p;
+          pf[f][kf >> 1][(kf & 1) * 4 + r] = (half_t)p;
+        }
+      if constexpr (!ONES) l_run[f] += ps;
+    }
+  };
+  auto pv = [&](int slot, const h8 (&pf)[QF][2]) {
+    const char* Vs = Vring + slot * VBYTES;
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int pk = 0; pk < 2; ++pk) {
+        const h8 vfrag = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          o[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf[f][pk], o[i][f], 0, 0, 0);
+      }
+    }
+  };
+
+  auto rescale_to = [&](const float (&mx)[QF]) {   // new running max; rescale O (and l) only when some lane's max grew
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      const float m_new = fmaxf(m_cur[f], mx[f]);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_cur[f]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_cur[f] - m_new);
+        if constexpr (!ONES) l_run[f] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DF; ++i) o[i][f] *= alpha;
+      }
+      m_cur[f] = m_new;
+    }
+  };
+#pragma unroll
+  for (int f = 0; f < QF; ++f) m_cur[f] = -INFINITY;
+
+  if (nfull > 0) {
+    // ---- prologue: K(0), K(1), V(0) in flight together; S(0) and its row max ---------------------------------------
+    issue_full_k(0, 0);
+    issue_full_k(1, 1);
+    issue_full_v(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f4 st[QF][4];
+    qk(0, st);
+    row_max(st, m_cur);
+    for (int t = 0; t + 1 < nfull; ++t) {
+      // K(t+1) and V(t) have landed for every wave; the slots of K(t) (its S^T is in registers) and V(t-1) are free
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      issue_full_k(t + 2, t & 1);
+      issue_full_v(t + 1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // ONE branch-free block whose instruction order is PINNED step by step (left alone, hipcc emits all exponentials first
+      // and all MFMAs after them: no overlap inside the wave).  A: every QK^T MFMA of tile t+1 is followed by its share of the
+      // exponentials of tile t (a pair of scores -> fma, exp2, cvt_pk); the K fragments are read up front.  B: every PV MFMA of
+      // tile t is followed by a slice of the row-max chain of tile t+1.
+      h8 pf[QF][2];
+      f4 st2[QF][4];
+      float mx[QF];
+      {
+        const char* Ks = Kring + ((t + 1) & 1) * KBYTES;
+        const char* Vs = Vring + (t & 1) * VBYTES;
+        h8 kfr[4][KSTEPS];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+          const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks)
+            kfr[kf][ks] = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+        }
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+          for (int kf = 0; kf < 4; ++kf) st2[f][kf] = f4{0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] float ps[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) ps[f] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NA = 4 * KSTEPS * QF;      // MFMAs of A
+        constexpr int NP = 8 * QF;               // score pairs of tile t
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int kf = i / (KSTEPS * QF), ks = (i / QF) % KSTEPS, f = i % QF;
+          st2[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], st2[f][kf], 0, 0, 0);
+#pragma unroll
+          for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs
+            const int pf_ = pp / 8, pkf = (pp % 8) / 2, pr = (pp % 2) * 2;
+            const float p0 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr] * g.c - m_cur[pf_]);
+            const float p1 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr + 1] * g.c - m_cur[pf_]);
+            if constexpr (!ONES) ps[pf_] += p0 + p1;
+            pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr] = (half_t)p0;
+            pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr + 1] = (half_t)p1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!ONES) {
+#pragma unroll
+          for (int f = 0; f < QF; ++f) l_run[f] += ps[f];
+        }
+        // B
+        h8 vfr[DF][2];
+#pragma unroll
+        for (int i = 0; i < DF; ++i) {
+          const int row = i * 16 + lr;
+#pragma unroll
+          for (int pk = 0; pk < 2; ++pk) vfr[i][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+        }
+#pragma unroll
+        for (int f = 0; f < QF; ++f) mx[f] = st2[f][0][0];
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NB = DF * 2 * QF;          // MFMAs of B
+        constexpr int NX = 16 * QF;              // fmax steps of the row-max chains
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int di = i / (2 * QF), pk = (i / QF) % 2, f = i % QF;
+          o[di][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[di][pk], pf[f][pk], o[di][f], 0, 0, 0);
+#pragma unroll
+          for (int x = (i * NX) / NB; x < ((i + 1) * NX) / NB; ++x) {
+            const int xf = x / 16, xe = x % 16;
+            mx[xf] = fmaxf(mx[xf], st2[xf][xe >> 2][xe & 3]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+          float v = mx[f];
+          v = fmaxf(v, __shfl_xor(v, 16, 64));
+          v = fmaxf(v, __shfl_xor(v, 32, 64));
+          mx[f] = v * g.c;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      rescale_to(mx);
+#pragma unroll
+      for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) st[f][kf] = st2[f][kf];
+    }
+    {  // last full tile: its V was issued in the previous iteration (or in the prologue)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      h8 pf[QF][2];
+      exp_part(st, pf);
+      pv((nfull - 1) & 1, pf);
+    }
+  }
+  // ---- partial last tiles of the two segments (cross-attention's 77 keys, odd test sizes): plain sequential online softmax
+#pragma unroll 1
+  for (int sgi = 0; sgi < 2; ++sgi) {
+    const bool s1 = sgi == 1;
+    const int nseg = s1 ? (t1 ? g.n1 : 0) : g.n0;
+    const int kv0 = nseg & ~63;
+    if (kv0 == nseg) continue;       // wave- and block-uniform: the segment ends on a tile boundary (or is absent)
+    __syncthreads();                 // every wave is done with slot 0 of both rings
+    issue_k(true, s1, kv0, 0);
+    issue_v(true, s1, kv0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f4 st[QF][4];
+    qk(0, st);
+    mask_tail(kv0, nseg, st);
+    float mx[QF];
+    row_max(st, mx);
+    rescale_to(mx);
+    h8 pf[QF][2];
+    exp_part(st, pf);
+    pv(0, pf);
+  }
+
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    float l;
+    if constexpr (ONES) {
+      l = __shfl(o[LI][f][LR], LG * 16 + lr, 64);   // O^T[D][q = lr] sits in lane group LG
+    } else {
+      l = l_run[f];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    const int row = qbase + f * 16 + lr;
+    if (row >= g.nq) continue;
+    half_t* op = g.out + b * g.out_bs + (long long)row * g.ld_out + h * D;
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int d = i * 16 + lg * 4;
+      if (d < D) {
+        h4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[i][f][r] * inv);
+        *reinterpret_cast<h4*>(op + d) = ov;
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int D, int QF>
+int launch_v3(const AttnArgs& g, hipStream_t s) {
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
+  constexpr int VJ = (DF * 16 * 8 + 255) / 256;
+  constexpr size_t lds = (size_t)2 * (64 * CL * 16 + VJ * 4096);
+  static bool attr_set[64] = {};
+  if (lds > 65536) {
+    int devi = 0;
+    MD_HIP_CHECK(hipGetDevice(&devi));
+    if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v3<D, QF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (devi >= 0 && devi < 64) attr_set[devi] = true;
+    }
+  }
+  constexpr int BQ = 64 * QF;
+  dim3 grid((g.nq + BQ - 1) / BQ, g.heads, g.batch);
+  hipLaunchKernelGGL((attn_kernel_v3<D, QF>), grid, dim3(256), lds, s, g);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 template <int D, int QF, int MAXST = 2>
 int launch_v2(const AttnArgs& g, hipStream_t s) {
   constexpr int DK = (D + 31) / 32 * 32;
@@ -504,11 +923,15 @@ int launch_v2(const AttnArgs& g, hipStream_t s) {
   constexpr int STAGE = 64 * CL * 16 + VJ * 4096;
   constexpr int STAGES = (MAXST >= 3 && 3 * STAGE <= 64 * 1024) ? 3 : 2;
   constexpr size_t lds = (size_t)STAGES * STAGE;
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v2<D, QF, MAXST>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  static bool attr_set[64] = {};   // per device
+  if (lds > 65536) {
+    int devi = 0;
+    MD_HIP_CHECK(hipGetDevice(&devi));
+    if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v2<D, QF, MAXST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (devi >= 0 && devi < 64) attr_set[devi] = true;
+    }
   }
   constexpr int BQ = 64 * QF;
   dim3 grid((g.nq + BQ - 1) / BQ, g.heads, g.batch);
@@ -592,6 +1015,21 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
     return e ? atoi(e) : 3;
   }();
   const bool is_cross = p->n0 != p->nq;
+  static const int use_v3 = [] {  // MD_ATTN_V=3: software-pipelined kernel (v3) for the self / bank attention shapes
+    const char* e = getenv("MD_ATTN_V");
+    return (e && e[0] == '3') ? 1 : 0;
+  }();
+  if (v2_ok && use_v3) {
+    switch (p->d) {
+      case 40: return qf == 1 ? launch_v3<40, 1>(g, s) : launch_v3<40, 2>(g, s);
+      case 80: return qf == 1 ? launch_v3<80, 1>(g, s) : launch_v3<80, 2>(g, s);
+      case 160: return launch_v3<160, 1>(g, s);
+      case 32: return launch_v3<32, 1>(g, s);
+      case 64: return qf == 1 ? launch_v3<64, 1>(g, s) : launch_v3<64, 2>(g, s);
+      case 128: return launch_v3<128, 1>(g, s);
+      default: break;
+    }
+  }
   if (v2_ok && (dbg_mask & (is_cross ? 2 : 1))) {
     if ((dbg_mask & 4) && p->d == 40) return qf == 1 ? launch_v2<40, 1, 3>(g, s) : launch_v2<40, 2, 3>(g, s);  // bit2: 3-stage ring
     switch (p->d) {

@@ -173,6 +173,11 @@ ATTN_CASES = [
     ("d64_tiny", 1, 2, 16, 16, 16, 1, 64, True),
     ("d32_n4", 1, 2, 4, 4, 4, 1, 32, True),
     ("d128", 1, 2, 64, 64, 0, 0, 128, True),
+    # several full 64-key tiles + a partial one in BOTH segments (software-pipelined loop, then the sequential tail path)
+    ("d40_tails", 2, 2, 200, 200, 136, 1, 40, True),
+    ("d80_tails", 1, 2, 130, 330, 70, 1, 80, True),
+    ("d160_tails", 2, 1, 96, 160, 100, 2, 160, False),
+    ("d40_long", 1, 2, 128, 1024, 512, 1, 40, True),
 ]
 
 

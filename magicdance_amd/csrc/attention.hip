@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
 // Softmax denominator: where D is not a multiple of 16 (d = 40) the last 16-row fragment of O^T has free rows; row D of the V^T
 // tile in LDS is preset to ones (its DMA is skipped), so O^T[D][q] accumulates sum_kv P -- the row sum comes out of the PV MFMAs
 // (summing exactly the fp16 P that the numerator uses) and the per-score v_add disappears; otherwise the sum stays on the VALU.
-template <int D, int QF>
+template <int D, int QF, int P>
 __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DK = (D + 31) / 32 * 32;
@@ -522,15 +522,25 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   constexpr unsigned OOB = 0x80000000u;
   constexpr bool ONES = (D % 16) != 0;
   constexpr int LI = D / 16, LG = (D % 16) / 4, LR = D % 4;   // O^T fragment / lane group / register of row D
+  constexpr int R = P + 1;                                    // ring slots: loads run P tiles ahead of the MFMAs
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K slot 0, K slot 1, V slot 0, V slot 1
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // R K slots, then R V slots
   char* const Kring = smem;
-  char* const Vring = smem + 2 * KBYTES;
+  char* const Vring = smem + R * KBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qbase = blockIdx.x * BQ + wave * (16 * QF);
+  // XCD-aware placement (workgroup id -> XCD id % 8 is the observed dispatch): every XCD gets a CONTIGUOUS range of logical
+  // blocks = whole (head, sample) pairs, so the K / V^T tiles its 32 CUs stream stay inside that XCD's 4 MB L2 (at 64^2 all
+  // heads x samples are 7.9 MB; interleaved over the XCDs every tile came from the Infinity Cache); sample is the FASTEST index
+  // of the pair so that each XCD holds as many long (bank-reading) workgroups as short ones.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nqb = (g.nq + BQ - 1) / BQ;
+  const int hb = logical / nqb, qb = logical - hb * nqb;
+  const int b = hb % g.batch, h = hb / g.batch;
+  const int qbase = qb * BQ + wave * (16 * QF);
 
   h8 qf[QF][KSTEPS];
 #pragma unroll
@@ -606,7 +616,8 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
     const unsigned vsoff = live ? (unsigned)kv0 * 2u : 0u;
 #pragma unroll
     for (int j = 0; j < VJ; ++j) {
-      if (ONES && (j * 4 + wave) * 8 >= D) continue;   // rows D.. of the tile are preset (ones row + zero rows): never overwritten
+      if ((j * 4 + wave) * 8 >= D) continue;   // rows D.. : preset (ones row + zeros) when ONES, never read otherwise -- and an
+                                               // instruction whose lanes are ALL out of range must not sit in a counted-vmcnt queue
       if (s1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv1, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
                                                  (kv0 + vkv_[j] < nseg) ? vo1[j] : OOB, vsoff, 0, 0);
@@ -615,13 +626,31 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
                                                  (kv0 + vkv_[j] < nseg) ? vo0[j] : OOB, vsoff, 0, 0);
     }
   };
-  auto issue_full_k = [&](int t, int slot) { issue_k(t < nfull, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot); };
-  auto issue_full_v = [&](int t, int slot) { issue_v(t < nfull, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot); };
+  auto slot_of = [&](int t) { return R == 2 ? (t & 1) : (R == 4 ? (t & 3) : t % R); };
+  // full tile t of the pipelined loop (a K tile one past the end is replaced by a re-read of the last tile: every issued
+  // instruction keeps live lanes, the copy lands in a free slot and is never used)
+  auto issue_full_k = [&](int t) { const int tt = min(t, nfull - 1); issue_k(true, tt >= nf0, (tt >= nf0 ? tt - nf0 : tt) << 6, slot_of(t)); };
+  auto issue_full_v = [&](int t) { issue_v(true, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot_of(t)); };
+  // this wave's DMA instructions per load group {K tile, V tile}: V instructions whose 8 rows lie beyond D are not issued
+  int lpt = KJ;
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) lpt += ((j * 4 + wave) * 8 < D) ? 1 : 0;
+  auto wait_steady = [&]() {   // all but the newest P-1 load groups of this wave have landed (immediate operand: dispatch on the count)
+    const int n = (P - 1) * lpt;
+    if (P == 1 || n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define MD_VMCNT_CASE(N) else if (n == (N)) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
+    MD_VMCNT_CASE(2) MD_VMCNT_CASE(3) MD_VMCNT_CASE(4) MD_VMCNT_CASE(5) MD_VMCNT_CASE(6) MD_VMCNT_CASE(7) MD_VMCNT_CASE(8) MD_VMCNT_CASE(9)
+    MD_VMCNT_CASE(10) MD_VMCNT_CASE(11) MD_VMCNT_CASE(12) MD_VMCNT_CASE(13) MD_VMCNT_CASE(14) MD_VMCNT_CASE(15) MD_VMCNT_CASE(16)
+    MD_VMCNT_CASE(18) MD_VMCNT_CASE(20) MD_VMCNT_CASE(21) MD_VMCNT_CASE(22) MD_VMCNT_CASE(24) MD_VMCNT_CASE(26) MD_VMCNT_CASE(27)
+    MD_VMCNT_CASE(30) MD_VMCNT_CASE(33) MD_VMCNT_CASE(36) MD_VMCNT_CASE(39)
+#undef MD_VMCNT_CASE
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a count without a case: drain (always correct)
+  };
 
   if constexpr (ONES) {  // rows D .. DF*16-1 of both V slots: row D = ones, the rest zeros (128 B per row, any chunk order)
     static_assert(D % 8 == 0, "preset rows start on a DMA instruction boundary (8 rows)");
     constexpr int NPRE = (DF * 16 - D) * 8;   // 16-byte chunks per slot
-    for (int i = tid; i < 2 * NPRE; i += 256) {
+    for (int i = tid; i < R * NPRE; i += 256) {
       const int slot = i / NPRE, c = i - slot * NPRE;
       const half_t one = (c < 8) ? (half_t)1.0f : (half_t)0.0f;
       const h8 v = {one, one, one, one, one, one, one, one};
@@ -728,22 +757,31 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   for (int f = 0; f < QF; ++f) m_cur[f] = -INFINITY;
 
   if (nfull > 0) {
-    // ---- prologue: K(0), K(1), V(0) in flight together; S(0) and its row max ---------------------------------------
-    issue_full_k(0, 0);
-    issue_full_k(1, 1);
-    issue_full_v(0, 0);
+    // ---- prologue: K(0) and the load groups {K(i+1), V(i)}, i < P, in flight together; S(0) and its row max -------------
+    // Load group G(t) = {K(t+1+P), V(t+P)} is issued in iteration t (if V(t+P) exists); iteration t needs G(t-P) = {K(t+1), V(t)}.
+    issue_full_k(0);
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      if (i < nfull) {
+        issue_full_k(i + 1);
+        issue_full_v(i);
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f4 st[QF][4];
     qk(0, st);
     row_max(st, m_cur);
     for (int t = 0; t + 1 < nfull; ++t) {
-      // K(t+1) and V(t) have landed for every wave; the slots of K(t) (its S^T is in registers) and V(t-1) are free
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // K(t+1) and V(t) have landed for every wave (counted wait: the P-1 newer groups stay in flight -- one L2 / Infinity-Cache
+      // round trip takes longer than the MFMAs of one tile, so with a single tile of prefetch every iteration waited for its
+      // loads); the slots of K(t) (its S^T is in registers) and V(t-1) are free.  Near the end fewer groups are in flight: drain.
+      if (t + P <= nfull) wait_steady(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue_full_k(t + 2, t & 1);
-      issue_full_v(t + 1, (t + 1) & 1);
+      if (t + P < nfull) {
+        issue_full_k(t + 1 + P);
+        issue_full_v(t + P);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // ONE branch-free block whose instruction order is PINNED step by step (left alone, hipcc emits all exponentials first
       // and all MFMAs after them: no overlap inside the wave).  A: every QK^T MFMA of tile t+1 is followed by its share of the
@@ -753,8 +791,8 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       f4 st2[QF][4];
       float mx[QF];
       {
-        const char* Ks = Kring + ((t + 1) & 1) * KBYTES;
-        const char* Vs = Vring + (t & 1) * VBYTES;
+        const char* Ks = Kring + slot_of(t + 1) * KBYTES;
+        const char* Vs = Vring + slot_of(t) * VBYTES;
         h8 kfr[4][KSTEPS];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
@@ -836,7 +874,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       __syncthreads();
       h8 pf[QF][2];
       exp_part(st, pf);
-      pv((nfull - 1) & 1, pf);
+      pv(slot_of(nfull - 1), pf);
     }
   }
   // ---- partial last tiles of the two segments (cross-attention's 77 keys, odd test sizes): plain sequential online softmax
@@ -890,26 +928,27 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int D, int QF>
+template <int D, int QF, int P>
 int launch_v3(const AttnArgs& g, hipStream_t s) {
   constexpr int DK = (D + 31) / 32 * 32;
   constexpr int DF = (D + 15) / 16;
   constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
   constexpr int VJ = (DF * 16 * 8 + 255) / 256;
-  constexpr size_t lds = (size_t)2 * (64 * CL * 16 + VJ * 4096);
+  constexpr size_t lds = (size_t)(P + 1) * (64 * CL * 16 + VJ * 4096);
+  static_assert(lds <= 160 * 1024, "ring does not fit the 160 KB LDS");
   static bool attr_set[64] = {};
   if (lds > 65536) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v3<D, QF>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v3<D, QF, P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   constexpr int BQ = 64 * QF;
-  dim3 grid((g.nq + BQ - 1) / BQ, g.heads, g.batch);
-  hipLaunchKernelGGL((attn_kernel_v3<D, QF>), grid, dim3(256), lds, s, g);
+  dim3 grid(((g.nq + BQ - 1) / BQ) * g.heads * g.batch);
+  hipLaunchKernelGGL((attn_kernel_v3<D, QF, P>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -1015,19 +1054,37 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
     return e ? atoi(e) : 3;
   }();
   const bool is_cross = p->n0 != p->nq;
-  static const int use_v3 = [] {  // MD_ATTN_V=3: software-pipelined kernel (v3) for the self / bank attention shapes
+  static const int use_v3 = [] {  // default: software-pipelined kernel (v3); MD_ATTN_V=2 / 1 select the older kernels (A/B)
     const char* e = getenv("MD_ATTN_V");
-    return (e && e[0] == '3') ? 1 : 0;
+    return (e && (e[0] == '1' || e[0] == '2')) ? 0 : 1;
   }();
   if (v2_ok && use_v3) {
-    switch (p->d) {
-      case 40: return qf == 1 ? launch_v3<40, 1>(g, s) : launch_v3<40, 2>(g, s);
-      case 80: return qf == 1 ? launch_v3<80, 1>(g, s) : launch_v3<80, 2>(g, s);
-      case 160: return launch_v3<160, 1>(g, s);
-      case 32: return launch_v3<32, 1>(g, s);
-      case 64: return qf == 1 ? launch_v3<64, 1>(g, s) : launch_v3<64, 2>(g, s);
-      case 128: return launch_v3<128, 1>(g, s);
-      default: break;
+    // MD_ATTN_P=3: loads 3 tiles ahead (2 for the wide heads) with counted vmcnt.  Measured SLOWER than one tile of prefetch
+    // (d = 40, 64^2: 149 vs 139 us; profiles/round2_attention_*.txt): the kernel is VALU-bound (softmax), not latency-bound.
+    static const int deep = [] {
+      const char* e = getenv("MD_ATTN_P");
+      return (e && e[0] == '3') ? 1 : 0;
+    }();
+    if (deep) {
+      switch (p->d) {
+        case 40: return qf == 1 ? launch_v3<40, 1, 3>(g, s) : launch_v3<40, 2, 3>(g, s);
+        case 80: return qf == 1 ? launch_v3<80, 1, 3>(g, s) : launch_v3<80, 2, 3>(g, s);
+        case 160: return launch_v3<160, 1, 2>(g, s);
+        case 32: return launch_v3<32, 1, 3>(g, s);
+        case 64: return qf == 1 ? launch_v3<64, 1, 3>(g, s) : launch_v3<64, 2, 3>(g, s);
+        case 128: return launch_v3<128, 1, 2>(g, s);
+        default: break;
+      }
+    } else {
+      switch (p->d) {
+        case 40: return qf == 1 ? launch_v3<40, 1, 1>(g, s) : launch_v3<40, 2, 1>(g, s);
+        case 80: return qf == 1 ? launch_v3<80, 1, 1>(g, s) : launch_v3<80, 2, 1>(g, s);
+        case 160: return launch_v3<160, 1, 1>(g, s);
+        case 32: return launch_v3<32, 1, 1>(g, s);
+        case 64: return qf == 1 ? launch_v3<64, 1, 1>(g, s) : launch_v3<64, 2, 1>(g, s);
+        case 128: return launch_v3<128, 1, 1>(g, s);
+        default: break;
+      }
     }
   }
   if (v2_ok && (dbg_mask & (is_cross ? 2 : 1))) {

@@ -95,6 +95,11 @@ typedef struct {
    * out_lo (fp16 [M][ld_out], may be NULL; fp16 `out` only, columns < n_tr_begin) receives fp16(v - fp16(v)). */
   const void* res_lo;
   void* out_lo;
+  /* columns n < col_scale_end of the result (after bias) are multiplied by col_scale before any other epilogue step: the
+   * attention scale d^-0.5 * log2(e) folded into the q columns of the to_q / fused to_q|k|v projection (attention.py:171-176
+   * scales q.k^T; here q itself, while still fp32).  col_scale_end = 0 disables; multiple of 4. */
+  float col_scale;
+  int32_t col_scale_end;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
@@ -122,6 +127,9 @@ typedef struct {
   void* out; int64_t out_batch_stride; int32_t ld_out;       /* fp16 [B][Nq][ld_out] */
   int32_t batch, heads, nq, d;  /* d in 40 / 80 / 160 (SD-1.5) or 8,16,32,64,128 (test geometries) */
   float scale;             /* d^-0.5 */
+  int32_t q_prescaled;     /* ABI v2.  1: q already carries scale * log2(e) -- written that way by the projection GEMM (md_igemm
+                            * col_scale), i.e. folded in before the fp16 rounding of q -- so q.k is the logit in the exp2 domain and
+                            * `scale` is ignored; 0: the kernel applies scale * log2(e) itself */
 } md_attention_params;
 
 int md_attention(const md_attention_params* p, void* stream);

@@ -39,6 +39,7 @@ struct AttnArgs {
   int ld_out;
   int batch, heads, nq;
   float c;  // scale * log2(e)
+  int q_prescaled;  // q already carries scale * log2(e) (projection GEMM epilogue): scores come out in the exp2 domain
 };
 
 template <int D, int QF>
@@ -551,6 +552,10 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       const int d = ks * 32 + lg * 8;
       if (row < g.nq && d < D) v = *reinterpret_cast<const h8*>(g.q + b * g.q_bs + (long long)row * g.ld_q + h * D + d);
+      if (!g.q_prescaled) {   // generic callers: fold scale * log2(e) into Q here (the engine's projection GEMM does it in its
+#pragma unroll              // epilogue, before the fp16 rounding): the MFMAs then produce the scores in the exp2 domain
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * g.c);
+      }
       qf[f][ks] = v;
     }
   }
@@ -669,12 +674,17 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   for (int f = 0; f < QF; ++f) l_run[f] = 0.f;
 
   // S^T of one tile: 4 key fragments x QF query fragments
+  // The S^T accumulators start at -m (running max of the query column, exp2 domain) instead of 0: the MFMAs deliver S - m and
+  // the per-score subtraction of the online softmax disappears.
+  f4 negm[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) negm[f] = f4{0.f, 0.f, 0.f, 0.f};
   auto qk = [&](int slot, f4 (&st)[QF][4]) {
     const char* Ks = Kring + slot * KBYTES;
 #pragma unroll
     for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf) st[f][kf] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int kf = 0; kf < 4; ++kf) st[f][kf] = negm[f];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
       const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
@@ -697,17 +707,22 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
         for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
       }
   };
-  auto row_max = [&](const f4 (&st)[QF][4], float (&mx)[QF]) {   // scaled by c: the running max lives in the exp2 domain
+  auto max3 = [](float a, float b2, float c2) {   // one instruction (fmaxf on MFMA results gets a canonicalising v_max in front)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c2));
+    return r;
+  };
+  auto row_max = [&](const f4 (&st)[QF][4], float (&mx)[QF]) {   // per query column, over the tile's 64 keys
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      float v = st[f][0][0];
+      float v = max3(st[f][0][0], st[f][0][1], st[f][0][2]);
+      v = max3(v, st[f][0][3], st[f][1][0]);
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v = fmaxf(v, st[f][kf][r]);
+      for (int e = 5; e < 15; e += 2) v = max3(v, st[f][e >> 2][e & 3], st[f][(e + 1) >> 2][(e + 1) & 3]);
+      v = fmaxf(v, st[f][3][3]);
       v = fmaxf(v, __shfl_xor(v, 16, 64));
       v = fmaxf(v, __shfl_xor(v, 32, 64));
-      mx[f] = v * g.c;
+      mx[f] = v;
     }
   };
   auto exp_part = [&](const f4 (&st)[QF][4], h8 (&pf)[QF][2]) {   // P(t) = exp2(S c - m) as fp16 MFMA operands
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[f][kf][r] * g.c - m_cur[f]);
+          const float p = __builtin_amdgcn_exp2f(st[f][kf][r]);
           if constexpr (!ONES) ps += p;
           pf[f][kf >> 1][(kf & 1) * 4 + r] = (half_t)p;
         }
@@ -740,21 +755,31 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
     }
   };
 
-  auto rescale_to = [&](const float (&mx)[QF]) {   // new running max; rescale O (and l) only when some lane's max grew
+  // ``mx`` = row max of scores that were computed RELATIVE to the current running max (accumulator init -m).  The running max is
+  // moved only when some column's new maximum exceeds it by more than THR (exp2 domain): until then P = exp2(S - m) may reach
+  // 2^THR instead of 1 -- harmless, fp16 P keeps its 11 significant bits at any magnitude below 65504, numerator and
+  // denominator accumulate in fp32 and are scaled alike -- and no per-score fix-up is needed.  When it moves, the tile's scores,
+  // O and l are rescaled once.  THR = 0 in the sequential tail path and for the very first tile.
+  auto rescale_to = [&](const float (&mx)[QF], f4 (&st)[QF][4], float thr) {
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      const float m_new = fmaxf(m_cur[f], mx[f]);
-      if (__builtin_amdgcn_ballot_w64(m_new > m_cur[f]) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m_cur[f] - m_new);
+      if (__builtin_amdgcn_ballot_w64(mx[f] > thr) != 0) {
+        const float delta = fmaxf(mx[f], 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
         if constexpr (!ONES) l_run[f] *= alpha;
 #pragma unroll
         for (int i = 0; i < DF; ++i) o[i][f] *= alpha;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) st[f][kf] -= delta;
+        m_cur[f] += delta;
+        negm[f] = f4{-m_cur[f], -m_cur[f], -m_cur[f], -m_cur[f]};
       }
-      m_cur[f] = m_new;
     }
   };
+  constexpr float THR = 6.0f;
 #pragma unroll
-  for (int f = 0; f < QF; ++f) m_cur[f] = -INFINITY;
+  for (int f = 0; f < QF; ++f) m_cur[f] = 0.f;   // set by the first tile (its scores are computed against 0)
+  bool first = true;
 
   if (nfull > 0) {
     // ---- prologue: K(0) and the load groups {K(i+1), V(i)}, i < P, in flight together; S(0) and its row max -------------
@@ -770,7 +795,18 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
     __syncthreads();
     f4 st[QF][4];
     qk(0, st);
-    row_max(st, m_cur);
+    {  // first tile: its row max becomes the running max (O is still zero)
+      float mx0[QF];
+      row_max(st, mx0);
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        m_cur[f] = mx0[f];
+        negm[f] = f4{-mx0[f], -mx0[f], -mx0[f], -mx0[f]};
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) st[f][kf] -= mx0[f];
+      }
+      first = false;
+    }
     for (int t = 0; t + 1 < nfull; ++t) {
       // K(t+1) and V(t) have landed for every wave (counted wait: the P-1 newer groups stay in flight -- one L2 / Infinity-Cache
       // round trip takes longer than the MFMAs of one tile, so with a single tile of prefetch every iteration waited for its
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
 #pragma unroll
         for (int f = 0; f < QF; ++f)
 #pragma unroll
-          for (int kf = 0; kf < 4; ++kf) st2[f][kf] = f4{0.f, 0.f, 0.f, 0.f};
+          for (int kf = 0; kf < 4; ++kf) st2[f][kf] = negm[f];
         [[maybe_unused]] float ps[QF];
 #pragma unroll
         for (int f = 0; f < QF; ++f) ps[f] = 0.f;
@@ -818,8 +854,8 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
 #pragma unroll
           for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs
             const int pf_ = pp / 8, pkf = (pp % 8) / 2, pr = (pp % 2) * 2;
-            const float p0 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr] * g.c - m_cur[pf_]);
-            const float p1 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr + 1] * g.c - m_cur[pf_]);
+            const float p0 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr]);
+            const float p1 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr + 1]);
             if constexpr (!ONES) ps[pf_] += p0 + p1;
             pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr] = (half_t)p0;
             pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr + 1] = (half_t)p1;
@@ -839,18 +875,18 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int pk = 0; pk < 2; ++pk) vfr[i][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
         }
 #pragma unroll
-        for (int f = 0; f < QF; ++f) mx[f] = st2[f][0][0];
+        for (int f = 0; f < QF; ++f) mx[f] = -INFINITY;
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NB = DF * 2 * QF;          // MFMAs of B
-        constexpr int NX = 16 * QF;              // fmax steps of the row-max chains
+        constexpr int NX = 8 * QF;               // v_max3 steps of the row-max chains (two scores each)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int di = i / (2 * QF), pk = (i / QF) % 2, f = i % QF;
           o[di][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[di][pk], pf[f][pk], o[di][f], 0, 0, 0);
 #pragma unroll
           for (int x = (i * NX) / NB; x < ((i + 1) * NX) / NB; ++x) {
-            const int xf = x / 16, xe = x % 16;
-            mx[xf] = fmaxf(mx[xf], st2[xf][xe >> 2][xe & 3]);
+            const int xf = x / 8, xe = (x % 8) * 2;
+            mx[xf] = max3(mx[xf], st2[xf][xe >> 2][xe & 3], st2[xf][xe >> 2][(xe & 3) + 1]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -859,11 +895,11 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           float v = mx[f];
           v = fmaxf(v, __shfl_xor(v, 16, 64));
           v = fmaxf(v, __shfl_xor(v, 32, 64));
-          mx[f] = v * g.c;
+          mx[f] = v;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      rescale_to(mx);
+      rescale_to(mx, st2, THR);
 #pragma unroll
       for (int f = 0; f < QF; ++f)
 #pragma unroll
@@ -894,7 +930,18 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
     mask_tail(kv0, nseg, st);
     float mx[QF];
     row_max(st, mx);
-    rescale_to(mx);
+    if (first) {   // no full tile before: this tile's row max becomes the running max (scores were computed against 0)
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        m_cur[f] = mx[f];
+        negm[f] = f4{-mx[f], -mx[f], -mx[f], -mx[f]};
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) st[f][kf] -= mx[f];
+      }
+      first = false;
+    } else {
+      rescale_to(mx, st, 0.f);
+    }
     h8 pf[QF][2];
     exp_part(st, pf);
     pv(0, pf);
@@ -1026,7 +1073,8 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   g.batch = p->batch;
   g.heads = p->heads;
   g.nq = p->nq;
-  g.c = p->scale * 1.4426950408889634f;
+  g.q_prescaled = p->q_prescaled ? 1 : 0;
+  g.c = g.q_prescaled ? 1.0f : p->scale * 1.4426950408889634f;   // prescaled q: the scores already are log2-domain logits
   hipStream_t s = (hipStream_t)stream;
   const double nkv = (double)p->n0 + (double)g.n1 * ((double)(g.n1_batches < p->batch ? g.n1_batches : p->batch) / p->batch);
   char tag[96];

@@ -43,6 +43,8 @@ struct IgemmArgs {
   int act;
   void* out;
   half_t* out_lo;
+  float col_scale;
+  int col_scale_end;
   int ld_out;
   int out_f32;
   half_t* out_t;
@@ -68,6 +70,7 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
     const f4 bv = *reinterpret_cast<const f4*>(g.bias + (long long)b * g.bias_bs + n);
     v += bv;
   }
+  if (n < g.col_scale_end) v *= g.col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
   if (g.act == MD_ACT_SILU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = md::silu_f(v[i]);
@@ -688,6 +691,7 @@ int validate(const md_igemm_params* p) {
   if (p->res && (p->ld_res & 3)) return MD_ERR_BAD_ARG;
   if (p->res_lo && !p->res) return MD_ERR_BAD_ARG;
   if (p->out_lo && (p->out_f32 || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;
+  if (p->col_scale_end < 0 || (p->col_scale_end & 3) || (p->col_scale_end && p->act == MD_ACT_GEGLU)) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
   if (p->bias_batch_stride & 3) return MD_ERR_BAD_ARG;
@@ -807,6 +811,8 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.res = (const half_t*)p->res;
   g.res_lo = (const half_t*)p->res_lo;
   g.out_lo = (half_t*)p->out_lo;
+  g.col_scale = p->col_scale;
+  g.col_scale_end = p->col_scale_end;
   g.ld_res = p->ld_res;
   g.act = p->act;
   g.out = p->out;

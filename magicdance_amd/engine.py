@@ -295,7 +295,7 @@ class NetEngine:
         return buf
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
-             out_f32=False, out=None, ln=None, lo=False):
+             out_f32=False, out=None, ln=None, lo=False, col_scale=None):
         """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act.  ``lo``: the output is a link of
         a residual chain -- also store what the fp16 rounding dropped (Act.lo), to be added back by the next link."""
         hin, win = x.h, x.w
@@ -312,7 +312,7 @@ class NetEngine:
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
-                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo)
+                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale)
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
         return Act(out, x.b, hout, wout, nout, out_lo)
 
@@ -420,6 +420,12 @@ class NetEngine:
             skip = x
         return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True)
 
+    @staticmethod
+    def qscale(dh):
+        """attention scale d^-0.5 (attention.py:171-176) times log2(e): folded into q by the projection GEMM's epilogue (while
+        the value is still fp32), so that md_attention's scores come out of the MFMAs as exp2-domain logits"""
+        return float(dh) ** -0.5 * 1.4426950408889634
+
     def attention(self, q, ld_q, k0, ld_k0, vt0, ld_vt0, n0, b, nq, heads, dh, *, k0_bs, vt0_bs, seg1=None, n1_batches=0):
         c = heads * dh
         out = self.arena.alloc((b, nq, c), F16)
@@ -428,7 +434,7 @@ class NetEngine:
             k1, ld_k1, vt1, ld_vt1, n1, k1_bs, vt1_bs = seg1
             kw = dict(k1=k1, vt1=vt1, n1=n1, ld_k1=ld_k1, ld_vt1=ld_vt1, k1_bs=k1_bs, vt1_bs=vt1_bs, n1_batches=n1_batches)
         ops.attention(q, k0, vt0, out, batch=b, heads=heads, nq=nq, d=dh, n0=n0, ld_q=ld_q, ld_k0=ld_k0, ld_vt0=ld_vt0,
-                      ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, **kw)
+                      ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, q_prescaled=True, **kw)
         _chk(out, f"attention b={b} nq={nq} n0={n0} d={dh} seg1={None if seg1 is None else seg1[4]}")
         return out
 
@@ -457,10 +463,10 @@ class NetEngine:
             if n1 is None:   # norm1 folded into the projection
                 wl, s1, s0 = blk["qkv_ln"]
                 ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
-                          n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), ln=(s1, s0, 1e-5))
+                          n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), ln=(s1, s0, 1e-5), col_scale=(self.qscale(dh), c))
             else:
                 ops.igemm(n1.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
-                          out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws())
+                          out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), col_scale=(self.qscale(dh), c))
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
@@ -486,10 +492,10 @@ class NetEngine:
             # cross attention to the text context (attention.py:318)
             if "q2_ln" in blk:
                 wl, s1, s0 = blk["q2_ln"]
-                q2 = self.conv(Act(t.t, b, 1, n, c), wl, c, k=1, ln=(s1, s0, 1e-5))
+                q2 = self.conv(Act(t.t, b, 1, n, c), wl, c, k=1, ln=(s1, s0, 1e-5), col_scale=(self.qscale(dh), c))
             else:
                 n2 = self.ln(t, blk["ln2"])
-                q2 = self.conv(Act(n2.t, b, 1, n, c), blk["q2_w"], c, k=1)
+                q2 = self.conv(Act(n2.t, b, 1, n, c), blk["q2_w"], c, k=1, col_scale=(self.qscale(dh), c))
             kc, vtc, bc, tk, ldvc = ctx_kv[ctx_idx[0]]
             ctx_idx[0] += 1
             assert bc == 1 or bc == b, "context batch must be 1 or match the sample batch"

@@ -23,8 +23,9 @@ RECORD = None
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None):
-    """See md_igemm.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
+          col_scale=None):
+    """See md_igemm.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
     p.a0, p.a1, p.c0, p.c1 = _p(a0), _p(a1), c0, c1
@@ -34,6 +35,8 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.bias, p.bias_batch_stride = _p(bias), bias_batch_stride
     p.res, p.ld_res = _p(res), ld_res
     p.res_lo, p.out_lo = _p(res_lo), _p(out_lo)
+    if col_scale is not None:
+        p.col_scale, p.col_scale_end = float(col_scale[0]), int(col_scale[1])
     p.act = act
     p.out, p.ld_out, p.out_f32 = _p(out), (ld_out if ld_out is not None else n), int(out_f32)
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
@@ -49,7 +52,7 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
 
 
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False):
     lib = _lib.load()
     p = AttentionParams()
     p.q, p.q_batch_stride, p.ld_q = _p(q), q_bs, ld_q
@@ -61,6 +64,7 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
     p.out, p.out_batch_stride, p.ld_out = _p(out), out_bs, ld_out
     p.batch, p.heads, p.nq, p.d = batch, heads, nq, d
     p.scale = float(d) ** -0.5 if scale is None else scale
+    p.q_prescaled = int(q_prescaled)
     _lib.check(lib.md_attention(C.byref(p), stream_ptr()), "md_attention")
     if RECORD is not None:
         nb1 = min(n1_batches, batch) if k1 is not None else 0

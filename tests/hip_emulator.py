@@ -19,7 +19,8 @@ def _mem(t, size, stride):
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
-          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None):
+          n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
+          col_scale=None):
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -48,6 +49,8 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
             y = y + _mem(bias, (batch, 1, n), (bias_batch_stride, 0, 1))
         else:
             y = y + _mem(bias, (n,), (1,))
+    if col_scale is not None:
+        y = torch.cat([y[..., :col_scale[1]] * col_scale[0], y[..., col_scale[1]:]], -1)
     ld_out = n if ld_out is None else ld_out
     if act == 2:  # GEGLU on 16-row interleaved packing
         y = y.reshape(batch, tokens, n // 32, 2, 16)
@@ -73,8 +76,10 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
 
 
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False):
     scale = d ** -0.5 if scale is None else scale
+    if q_prescaled:   # q carries scale * log2(e): q.k is the log2-domain logit
+        scale = math.log(2.0)
     qq = _mem(q, (batch, heads, nq, d), (q_bs, d, ld_q, 1)).float()
     kk = _mem(k0, (batch, heads, n0, d), (k0_bs, d, ld_k0, 1)).float()
     vv = _mem(vt0, (batch, heads, n0, d), (vt0_bs, d * ld_vt0, 1, ld_vt0)).float()

@@ -219,6 +219,31 @@ def test_attention(dev, case):
     assert _err(out, ref) <= 4e-3, name
 
 
+def test_attention_prescaled_q_and_col_scale(dev):
+    """ABI v2: md_igemm col_scale folds d^-0.5 * log2(e) into the q columns of a fused q|k projection while the value is still
+    fp32; md_attention q_prescaled then takes q.k as the exp2-domain logit.  Together they must reproduce softmax(q k^T d^-0.5) v."""
+    from magicdance_amd import ops
+    b, heads, n, d = 2, 4, 320, 40
+    c = heads * d
+    x = _rand((b, n, c), 1, dev).to(F16)
+    wqk = _rand((2 * c, c), 2, dev, c ** -0.5)
+    v = _rand((b, n, c), 3, dev).to(F16)
+    qs = d ** -0.5 * 1.4426950408889634
+    qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
+    ops.igemm(x, wqk.to(F16).contiguous(), 2 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
+              col_scale=(qs, c))
+    ref_qk = x.float() @ wqk.half().float().t()
+    assert _err(qk[..., :c], ref_qk[..., :c] * qs) <= 4e-3 and _err(qk[..., c:], ref_qk[..., c:]) <= 4e-3
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty((b, n, c), dtype=F16, device=dev)
+    ops.attention(qk, qk[:, :, c:], vt, out, batch=b, heads=heads, nq=n, d=d, n0=n, ld_q=2 * c, ld_k0=2 * c, ld_vt0=n, ld_out=c,
+                  q_bs=n * 2 * c, k0_bs=n * 2 * c, vt0_bs=c * n, out_bs=n * c, q_prescaled=True)
+    sp = lambda t: t.float().reshape(b, n, heads, d).permute(0, 2, 1, 3)  # noqa: E731
+    s_ = torch.einsum("bhid,bhjd->bhij", sp(ref_qk[..., :c].half()), sp(qk[..., c:])) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", s_.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, n, c)
+    assert _err(out, ref) <= 4e-3
+
+
 def test_attention_spike_rescale(dev):
     """online-softmax rescale path: one key dominates from a late tile on (running max jumps)."""
     from magicdance_amd import ops

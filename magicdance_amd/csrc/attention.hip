@@ -707,7 +707,11 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
         for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
       }
   };
-  auto max3 = [](float a, float b2, float c2) {   // one instruction (fmaxf on MFMA results gets a canonicalising v_max in front)
+  // v_max3_f32 by hand: fmaxf on MFMA results gets a canonicalising v_max in front of every operand.  hipcc pads NO hazards
+  // inside an asm statement, and an MFMA result needs wait states before a VALU may read it: max3 is used ONLY in block B of the
+  // pipelined loop, where the scores it reads were produced a whole block of MFMAs earlier; row_max (first tile, partial tiles)
+  // reads scores straight after their MFMAs and stays on compiler-generated fmaxf.
+  auto max3 = [](float a, float b2, float c2) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c2));
     return r;
@@ -715,11 +719,11 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   auto row_max = [&](const f4 (&st)[QF][4], float (&mx)[QF]) {   // per query column, over the tile's 64 keys
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      float v = max3(st[f][0][0], st[f][0][1], st[f][0][2]);
-      v = max3(v, st[f][0][3], st[f][1][0]);
+      float v = st[f][0][0];
 #pragma unroll
-      for (int e = 5; e < 15; e += 2) v = max3(v, st[f][e >> 2][e & 3], st[f][(e + 1) >> 2][(e + 1) & 3]);
-      v = fmaxf(v, st[f][3][3]);
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaxf(v, st[f][kf][r]);
       v = fmaxf(v, __shfl_xor(v, 16, 64));
       v = fmaxf(v, __shfl_xor(v, 32, 64));
       mx[f] = v;
@@ -1106,7 +1110,15 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
     const char* e = getenv("MD_ATTN_V");
     return (e && (e[0] == '1' || e[0] == '2')) ? 0 : 1;
   }();
-  if (v2_ok && use_v3) {
+  // v3 where it measured faster than v2 (profiles/round2_attention_microbench.txt): d = 40 (self / bank attention at 64^2,
+  // 1.17-1.27x), d = 80 with 64-row query blocks (1.3x); the 77-key cross attention, d = 80 with 128-row blocks (252 VGPRs) and
+  // d = 160 stay on v2.  Test geometries (d = 32 / 64 / 128) run v3.  MD_ATTN_V=3 forces v3 everywhere it exists.
+  static const int force_v3 = [] {
+    const char* e = getenv("MD_ATTN_V");
+    return (e && e[0] == '3') ? 1 : 0;
+  }();
+  const bool v3_pick = force_v3 || (!is_cross && (p->d == 40 || (p->d == 80 && qf == 1) || p->d == 32 || p->d == 64 || p->d == 128));
+  if (v2_ok && use_v3 && v3_pick) {
     // MD_ATTN_P=3: loads 3 tiles ahead (2 for the wide heads) with counted vmcnt.  Measured SLOWER than one tile of prefetch
     // (d = 40, 64^2: 149 vs 139 us; profiles/round2_attention_*.txt): the kernel is VALU-bound (softmax), not latency-bound.
     static const int deep = [] {

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 > gpurun_out/r2e_pytest.log
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r2e_pytest.log
 timeout 200 python tools/attn_bench.py > gpurun_out/r2e_attn_bench_v3.txt 2>&1
 MD_ATTN_V=2 timeout 200 python tools/attn_bench.py > gpurun_out/r2e_attn_bench_v2.txt 2>&1
 timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-extra > gpurun_out/r2e_bench.log 2>&1

@@ -172,6 +172,10 @@ int md_add_f16(const void* a, const void* b, void* out, int64_t n, int64_t b_per
  * AttnBlock.forward, ldm/modules/diffusionmodules/model.py:179-203), whose QK^T and PV contractions run on md_igemm. */
 int md_softmax_rows(const float* s, int64_t ld_s, void* p, int64_t ld_p, int32_t rows, int32_t cols, float scale,
                     void* stream);
+/* Decoded frames -> image bytes for the JPG writer: NCHW fp32 [B][c][hw] -> NHWC uint8 [B][hw][c],
+ * out = uint8(clamp(x * scale + bias, 0, 1) * 255 + 0.5)  (torchvision save_image's mul(255).add(0.5).clamp(0,255) after the
+ * scripts' clamp(-1,1).add(1).mul(0.5): test_any_image_pose.py:255-262, test_tiktok.py:283-288). c <= 4. */
+int md_image_to_u8(const float* x, void* out, int32_t batch, int32_t c, int32_t hw, float scale, float bias, void* stream);
 /* sinusoidal timestep embedding (ldm/modules/diffusionmodules/util.py:189-209): out fp32 [nt][dim] */
 int md_timestep_embedding(const float* t, float* out, int32_t nt, int32_t dim, float max_period, void* stream);
 /* y[r][n] = bias[n] + sum_k act(x[r][k]) * w[n][k]; x fp32 [rows][k], w fp16 [n][k], y fp32; rows <= 64.

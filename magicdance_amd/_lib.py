@@ -66,6 +66,7 @@ SIGNATURES = {
     "md_nchw_to_nhwc_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "md_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "md_add_f16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "md_image_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
     "md_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "md_gemv_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "md_select_row_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),

@@ -121,6 +121,19 @@ __global__ __launch_bounds__(256) void gather_rows(const uint4* __restrict__ tab
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long long)gridDim.x * 256) d[i] = src[i];
 }
 
+// decoded frames -> image bytes: out[b][p][c] = uint8(clamp(x[b][c][p] * scale + bias, 0, 1) * 255 + 0.5)
+__global__ __launch_bounds__(256) void image_to_u8(const float* __restrict__ x, unsigned char* __restrict__ out, int c, int hw,
+                                                   float scale, float bias, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, p): one pixel per thread
+  if (i >= total) return;
+  const long long b = i / hw;
+  const int p = (int)(i - b * hw);
+  for (int ch = 0; ch < c; ++ch) {
+    const float v = fminf(fmaxf(x[(b * c + ch) * hw + p] * scale + bias, 0.f), 1.f);
+    out[i * c + ch] = (unsigned char)(v * 255.0f + 0.5f);
+  }
+}
+
 __global__ void counter_add(int* counter, int delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *counter += delta;
 }
@@ -238,6 +251,18 @@ extern "C" int md_gather_rows(const void* table, const int64_t* seg, int32_t nse
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(gather_rows, dim3((unsigned)gx, (unsigned)nseg), dim3(256), 0, s, (const uint4*)table,
                      (const long long*)seg, row_counter, row_offset, nrows, rows_per_block, (long long)block_units, (uint4*)dst);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_image_to_u8(const float* x, void* out, int32_t batch, int32_t c, int32_t hw, float scale, float bias,
+                              void* stream) {
+  if (!x || !out || batch <= 0 || c <= 0 || c > 4 || hw <= 0) return MD_ERR_BAD_ARG;
+  const long long total = (long long)batch * hw;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, (double)total * c * 5.0);
+  hipLaunchKernelGGL(image_to_u8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (unsigned char*)out, c, hw, scale,
+                     bias, total);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }

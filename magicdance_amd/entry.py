@@ -1,9 +1,11 @@
 """Entry-point glue shared by test_any_image_pose.py / test_tiktok.py (repo root): the reference scripts' CLI surface
 (test_any_image_pose.py:463-577, scripts/inference_any_image_pose.sh) and output layout
 (``local_image_dir/{itr}/gen_images|pose_maps/%03d.jpg``, test_any_image_pose.py:175-180,256-262) on top of the MI355X
-hot path.  Image I/O, VAE and CLIP are outside this round's scope: when the VAE / CLIP of the YAML cannot be built in
-this image the reference latent / text context must be supplied as tensors (``--ref_latent``, ``--context_embedding``) and
-latents are written instead of JPGs.  No training, no dataset loader, no DDP wrapper (inference never needed them)."""
+hot path, including test_tiktok.py's dataset-driven flow (magicdance_amd/tiktok.py: validation loader, ground-truth VAE round
+trip into ``gt_images``, ``condition.jpg``).  When the CLIP text encoder of the YAML cannot be built in this image (its weights
+are not shipped) the text context is supplied as a tensor (``--context_embedding``).  Frames of a sequence are sharded over the
+ranks in contiguous blocks; JPGs are produced by a GPU uint8 conversion + asynchronous device->host copy + writer thread.
+No training and no DDP wrapper (inference never needed them)."""
 import argparse
 import os
 
@@ -72,13 +74,17 @@ def build_parser():
     p.add_argument("--ref_latent", type=str, default=None, help=".pt [1,4,h,w] reference latent (VAE(ref)*scale_factor) when no VAE is built")
     p.add_argument("--context_embedding", type=str, default=None, help='.pt [1,77,768] text context (CLIP("")) when no CLIP is built')
     p.add_argument("--synthetic_weights", action="store_true", help="seeded random weights when no checkpoint is given (plumbing runs)")
+    p.add_argument("--tiktok_data_path", type=str, default=None, help="test_tiktok.py: frames root (reference: ./TikTok-v4/disco_test_set)")
+    p.add_argument("--tiktok_pose_path", type=str, default=None, help="test_tiktok.py: pose-map root (reference: ./TikTok-v4/pose_map_disco_test_set)")
     return p
 
 
-def _load_square_512(path, normalize):
-    """center_crop_to_512 / center_crop_pose_to_512 (test_any_image_pose.py:46-81): RandomResizedCrop(512, scale=(1,1),
-    ratio=(1,1)) degenerates to the centred square crop of side min(h, w), bilinear resize to 512, ToTensor
-    (+ Normalize(0.5, 0.5) for the reference image)."""
+def load_square(path, normalize, size=512, return_pil=False):
+    """center_crop_to_512 / center_crop_pose_to_512 (test_any_image_pose.py:46-81) and the dataset transforms
+    (test_tiktok.py:441-459): torchvision RandomResizedCrop(size, scale=(1,1), ratio=(1,1), BILINEAR) on a PIL image -- its
+    get_params draws w = h = round(sqrt(H W)), which fits only a square image (then the crop is the whole image); for any other
+    shape all 10 attempts fail and the documented fallback applies: the CENTRED square crop of side min(H, W) -- followed by
+    PIL's bilinear resize, ToTensor (+ Normalize(0.5, 0.5) for images).  Restated independently in oracle/preprocess_restatement.py."""
     from PIL import Image
     img = Image.open(path)
     if img.mode != "RGB":
@@ -86,9 +92,14 @@ def _load_square_512(path, normalize):
     w, h = img.size
     s = min(w, h)
     left, top = (w - s) // 2, (h - s) // 2
-    img = img.crop((left, top, left + s, top + s)).resize((512, 512), Image.BILINEAR)
-    t = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
-    return (t - 0.5) / 0.5 if normalize else t
+    crop = img.crop((left, top, left + s, top + s)).resize((size, size), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(crop, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
+    t = (t - 0.5) / 0.5 if normalize else t
+    return (t, img) if return_pil else t
+
+
+def _load_square_512(path, normalize):
+    return load_square(path, normalize, 512)
 
 
 def _save_jpg(t, path):
@@ -97,23 +108,14 @@ def _save_jpg(t, path):
     Image.fromarray(arr).save(path)
 
 
-def run(args, need_dataset=False):
+def _build_model(args, dev):
     import magicdance_amd as M
-    from . import parallel, synthetic
+    from . import synthetic
     from .cldm import _Unavailable
-    if args.local_cond_image_path is None or args.local_pose_path is None:
-        raise NotImplementedError("the TikTok dataset loader (dataset/tiktok_video_arnold_copy.py) is outside this build: pass "
-                                  "--local_cond_image_path and --local_pose_path" + (" (test_tiktok.py falls back to the dataset)" if need_dataset else ""))
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-    torch.manual_seed(args.seed)
     model = M.create_model(args.model_config or M.DEFAULT_CONFIG)
     if args.image_pretrain_dir and os.path.exists(args.image_pretrain_dir):
-        model.load_state_dict(M.load_state_dict(args.image_pretrain_dir, location="cpu"), strict=True)
+        # test_any_image_pose.py:371 loads strict, test_tiktok.py:392 with strict=False
+        model.load_state_dict(M.load_state_dict(args.image_pretrain_dir, location="cpu"), strict=not getattr(args, "_tiktok", False))
     elif args.synthetic_weights:
         for pre, mod in (("model.diffusion_model.", model.model.diffusion_model), ("appearance_control_model.", model.appearance_control_model),
                          ("pose_control_model.", model.pose_control_model), ("first_stage_model.", model.first_stage_model)):
@@ -125,53 +127,124 @@ def run(args, need_dataset=False):
         raise FileNotFoundError("--image_pretrain_dir checkpoint not found (use --synthetic_weights for a plumbing run)")
     model = model.to(dev).eval()
     model.only_mid_control = args.only_mid_control
-    h = args.image_size
-    model.image_size = h
-    have_vae = model.first_stage_model is not None and not isinstance(model.first_stage_model, _Unavailable)
+    model.image_size = args.image_size
+    return model
+
+
+def _contexts(args, model, dev):
+    """(c_cross, uc_cross): CLIP(text) and CLIP("") (test_any_image_pose.py:198,217-220) when the text encoder is built, else the
+    tensor given with --context_embedding (stand-in for CLIP(""), used for both) or a seeded synthetic one."""
+    from . import synthetic
+    from .cldm import _Unavailable
     have_clip = model.cond_stage_model is not None and not isinstance(model.cond_stage_model, _Unavailable)
-    pose_files = sorted(os.listdir(args.local_pose_path))
-    poses = torch.stack([_load_square_512(os.path.join(args.local_pose_path, f), normalize=False) for f in pose_files]).to(dev)
-    if have_vae:
-        ref_img = _load_square_512(args.local_cond_image_path, normalize=True).unsqueeze(0).to(dev)
-        ref = model.get_first_stage_encoding(model.encode_first_stage(ref_img))
-    elif args.ref_latent:
-        ref = torch.load(args.ref_latent).to(dev).float()
-    else:
-        print("[magicdance_amd] no VAE in this image and no --ref_latent: using a seeded synthetic reference latent")
-        ref = synthetic.synth_inputs((h, h), seed=0, device=dev)["ref"]
     if have_clip:
-        ctx = model.get_learned_conditioning([args.text_prompt or ""])
-    elif args.context_embedding:
+        text = args.text_prompt if args.text_prompt is not None else ""          # test_any_image_pose.py:181-192
+        return model.get_learned_conditioning([text]).float(), model.get_unconditional_conditioning(1).float()
+    if args.context_embedding:
         ctx = torch.load(args.context_embedding).to(dev).float()
     else:
         print('[magicdance_amd] no CLIP in this image and no --context_embedding: using a seeded synthetic context')
-        ctx = synthetic.synth_inputs((h, h), seed=0, device=dev)["ctx"]
-    x_T = torch.randn(1, model.channels, h, h, device=dev)                      # drawn ONCE for all frames (:201-202)
-    my = list(range(len(pose_files)))[rank::world] if world > 1 else list(range(len(pose_files)))
-    sampler = parallel.FrameShardedSampler(model, rank=rank, world=world)
-    out_dir = os.path.join(args.local_image_dir, "0")
-    for sub in ("gen_images", "pose_maps", "latents"):
+        ctx = synthetic.synth_inputs((args.image_size, args.image_size), seed=0, device=dev)["ctx"]
+    return ctx, ctx
+
+
+def render_sequence(args, model, sampler, writer, out_dir, cond_image, poses, ctx, uc_ctx, gt_images=None, ref_latent=None):
+    """visualize() of the entry scripts (test_any_image_pose.py:155-262, test_tiktok.py:191-288) for ONE reference image and its
+    pose sequence: VAE-encode the reference, draw x_T once for all frames (:201-202), sample this rank's contiguous block of
+    frames, decode, write ``gen_images / pose_maps (/ gt_images) / condition.jpg`` under ``out_dir``.  Returns this rank's latents."""
+    from .cldm import _Unavailable
+    dev = model.device
+    rank, world = sampler.rank, sampler.world
+    h = args.image_size
+    have_vae = model.first_stage_model is not None and not isinstance(model.first_stage_model, _Unavailable)
+    for sub in ("gen_images", "pose_maps", "latents") + (("gt_images",) if gt_images is not None else ()):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
+    if have_vae and cond_image is not None:
+        ref = model.get_first_stage_encoding(model.encode_first_stage(cond_image.unsqueeze(0).to(dev)))
+        if rank == 0:
+            writer.save(cond_image.unsqueeze(0).to(dev).float(), [os.path.join(out_dir, "condition.jpg")])
+    else:
+        ref = ref_latent
+    x_T = torch.randn(1, model.channels, h, h, device=dev)                      # drawn ONCE for all frames (:201-202)
+    f0, f1 = sampler.frame_block(len(poses), rank, world)
+    my = list(range(f0, f1))
+    my_poses = torch.stack([poses[i] for i in my]).to(dev) if my else torch.zeros((0, 3, 8 * h, 8 * h), device=dev)
     if args.control_mode == "controlnet_important" and args.wonoise:
-        z = sampler.sample_sequence(poses[my], ctx, ref, x_T, frames_per_batch=args.frames_per_batch,
-                                    ddim_steps=args.ddim_steps, scale=args.guidance_scale)
+        z = sampler.sample_sequence(my_poses, ctx, ref, x_T, frames_per_batch=args.frames_per_batch, ddim_steps=args.ddim_steps,
+                                    scale=args.guidance_scale)
     else:  # balance mode / noisy reference: the reference's per-frame loop through the generic sampler route
         zs = []
-        for i in my:
-            c = {"c_concat": [poses[i:i + 1]], "c_crossattn": [ctx], "image_control": [ref], "wonoise": args.wonoise, "overlap_sampling": False}
-            uc = {"c_concat": [poses[i:i + 1]], "c_crossattn": [ctx], "wonoise": args.wonoise, "overlap_sampling": False}
+        for j in range(len(my)):
+            c = {"c_concat": [my_poses[j:j + 1]], "c_crossattn": [ctx], "image_control": [ref], "wonoise": args.wonoise, "overlap_sampling": False}
+            uc = {"c_concat": [my_poses[j:j + 1]], "c_crossattn": [uc_ctx], "wonoise": args.wonoise, "overlap_sampling": False}
             if args.control_mode != "controlnet_important":
-                uc["image_control"] = [ref]
+                uc["image_control"] = [ref]                                         # :221-224
             zi, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=args.ddim_steps, eta=args.eta,
                                      unconditional_guidance_scale=args.guidance_scale, unconditional_conditioning=uc,
                                      inpaint=None, x_T=x_T)
             zs.append(zi)
-        z = torch.cat(zs, 0)
+        z = torch.cat(zs, 0) if zs else torch.zeros((0, model.channels, h, h), device=dev)
     for j, i in enumerate(my):
         torch.save(z[j:j + 1].cpu(), os.path.join(out_dir, "latents", "%03d.pt" % i))
-        _save_jpg(poses[i], os.path.join(out_dir, "pose_maps", "%03d.jpg" % i))
+        writer.save(my_poses[j:j + 1].float(), [os.path.join(out_dir, "pose_maps", "%03d.jpg" % i)], value_range=(0.0, 1.0))
         if have_vae:
-            img = model.decode_first_stage(z[j:j + 1])
-            _save_jpg((img[0] + 1.0) / 2.0, os.path.join(out_dir, "gen_images", "%03d.jpg" % i))
-    print(f"[magicdance_amd] rank {rank}: {len(my)} frame(s) -> {out_dir}" + ("" if have_vae else " (latents only: no VAE in this image)"))
+            writer.save(model.decode_first_stage(z[j:j + 1]).float(), [os.path.join(out_dir, "gen_images", "%03d.jpg" % i)])
+            if gt_images is not None:   # VAE round trip of the ground-truth frame (test_tiktok.py:273-279)
+                real = gt_images[i].unsqueeze(0).to(dev)
+                rec = model.decode_first_stage(model.get_first_stage_encoding(model.encode_first_stage(real)))
+                writer.save(rec.float(), [os.path.join(out_dir, "gt_images", "%03d.jpg" % i)])
+    print(f"[magicdance_amd] rank {rank}: frames [{f0}, {f1}) of {len(poses)} -> {out_dir}" + ("" if have_vae else " (latents only: no VAE in this image)"))
+    return z
+
+
+def run(args, need_dataset=False):
+    from . import parallel, synthetic, tiktok
+    from .cldm import _Unavailable
+    args._tiktok = need_dataset
+    use_dataset = args.local_cond_image_path is None or args.local_pose_path is None
+    if use_dataset and not need_dataset:
+        raise ValueError("test_any_image_pose.py needs --local_cond_image_path and --local_pose_path (test_batch_data is None there, "
+                         "test_any_image_pose.py:453)")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(args.seed)
+    model = _build_model(args, dev)
+    h = args.image_size
+    have_vae = model.first_stage_model is not None and not isinstance(model.first_stage_model, _Unavailable)
+    ctx, uc_ctx = _contexts(args, model, dev)
+    sampler = parallel.FrameShardedSampler(model, rank=rank, world=world)
+    writer = tiktok.AsyncImageWriter(dev)
+    ref_latent = None
+    if not have_vae:
+        ref_latent = torch.load(args.ref_latent).to(dev).float() if args.ref_latent else \
+            synthetic.synth_inputs((h, h), seed=0, device=dev)["ref"]
+    z = None
+    try:
+        if use_dataset:
+            # test_tiktok.py:461-517: one subject folder per iteration, frame 0 = reference image, frames 1.. = targets
+            ds = tiktok.tiktok_video_arnold_val(**({"data_path": args.tiktok_data_path, "pose_path": args.tiktok_pose_path}
+                                                   if args.tiktok_data_path else {}), rank=rank, world_size=world,
+                                                img_bin_limit=args.img_bin_limit, image_size=8 * h)
+            it = iter(ds)
+            for itr in range(min(args.num_train_steps, len(ds))):
+                batch = next(it, None)
+                if batch is None:
+                    break
+                z = render_sequence(args, model, sampler, writer, os.path.join(args.local_image_dir, str(itr)), batch["condition_image"],
+                                    batch["pose_map_list"], ctx, uc_ctx, gt_images=batch["image_list"], ref_latent=ref_latent)
+        else:
+            pose_files = sorted(os.listdir(args.local_pose_path))
+            poses = [load_square(os.path.join(args.local_pose_path, f), False, 8 * h) for f in pose_files]
+            cond = load_square(args.local_cond_image_path, True, 8 * h)
+            z = render_sequence(args, model, sampler, writer, os.path.join(args.local_image_dir, "0"), cond, poses, ctx, uc_ctx,
+                                ref_latent=ref_latent)
+    finally:
+        writer.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return z

@@ -115,6 +115,11 @@ def add_f16(a, b, out, n, b_period=None):
     return out
 
 
+def image_to_u8(x, out, batch, c, hw, scale, bias):
+    _lib.check(_lib.load().md_image_to_u8(_p(x), _p(out), batch, c, hw, scale, bias, stream_ptr()), "md_image_to_u8")
+    return out
+
+
 def timestep_embedding(t, out, nt, dim, max_period=10000.0):
     _lib.check(_lib.load().md_timestep_embedding(_p(t), _p(out), nt, dim, max_period, stream_ptr()),
                "md_timestep_embedding")

@@ -138,6 +138,12 @@ def add_f16(a, b, out, n, b_period=None):
     return out
 
 
+def image_to_u8(x, out, batch, c, hw, scale, bias):
+    v = (_mem(x, (batch, c, hw), (c * hw, hw, 1)).float() * scale + bias).clamp(0, 1)
+    _mem(out, (batch, hw, c), (hw * c, c, 1)).copy_((v * 255.0 + 0.5).to(torch.uint8).transpose(1, 2))
+    return out
+
+
 def timestep_embedding(t, out, nt, dim, max_period=10000.0):
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=F32) / half)
@@ -247,7 +253,7 @@ def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
     for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "layernorm", "nchw_to_nhwc_f16",
-                 "nhwc_to_nchw_f32", "add_f16", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
+                 "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)

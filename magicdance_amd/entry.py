@@ -137,14 +137,14 @@ def _contexts(args, model, dev):
     from . import synthetic
     from .cldm import _Unavailable
     have_clip = model.cond_stage_model is not None and not isinstance(model.cond_stage_model, _Unavailable)
+    if args.context_embedding:      # explicit tensor (stand-in for CLIP(""), used for both branches)
+        ctx = torch.load(args.context_embedding).to(dev).float()
+        return ctx, ctx
     if have_clip:
         text = args.text_prompt if args.text_prompt is not None else ""          # test_any_image_pose.py:181-192
         return model.get_learned_conditioning([text]).float(), model.get_unconditional_conditioning(1).float()
-    if args.context_embedding:
-        ctx = torch.load(args.context_embedding).to(dev).float()
-    else:
-        print('[magicdance_amd] no CLIP in this image and no --context_embedding: using a seeded synthetic context')
-        ctx = synthetic.synth_inputs((args.image_size, args.image_size), seed=0, device=dev)["ctx"]
+    print('[magicdance_amd] no CLIP in this image and no --context_embedding: using a seeded synthetic context')
+    ctx = synthetic.synth_inputs((args.image_size, args.image_size), seed=0, device=dev)["ctx"]
     return ctx, ctx
 
 

@@ -81,7 +81,10 @@ def head_slice(t, n=4):
     return (t[:, :n] if t.dim() == 3 else t[:, :, :1, :n]).contiguous().cpu().numpy()
 
 
-def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64, stage1=False):
+TINY_CLIP = dict(num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)   # ViT-L/14 text geometry, 2 thin layers
+
+
+def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64, stage1=False, tiny_clip=False):
     """The product model (magicdance_amd.cldm.ControlLDMReferenceOnlyPose, or the stage-1 ControlLDMReferenceOnly) built
     from the shipped YAML with the golden case's geometry, loaded with the seeded synthetic weights."""
     import magicdance_amd as M
@@ -96,6 +99,10 @@ def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", imag
     with torch.device("meta"):
         model = M.instantiate_from_config(cfg)
     model = model.to_empty(device=device)
+    if tiny_clip:   # the YAML's text-encoder target, built from its embedded config (no network), real (seeded HF-init) weights
+        from magicdance_amd import clip
+        torch.manual_seed(seed + 11)
+        model.cond_stage_model = clip.FrozenCLIPEmbedder(device=str(device), text_config=TINY_CLIP)
     model.register_schedule(timesteps=1000, linear_start=cfg["params"]["linear_start"], linear_end=cfg["params"]["linear_end"])
     model.logvar = torch.zeros(1000)
     sd = synth_weights(model_channels, num_heads, seed=seed, device="cpu", stage1=stage1)

@@ -1,0 +1,77 @@
+"""CPU: the text-conditioning wrapper (model_lib/ControlNet/ldm/modules/encoders/modules.py:88-131) without network
+access: config-only construction, the empty-prompt tokenizer, the cached CLIP("") embedding, and the checkpoint key adapter
+between the transformers 4.x and 5.x layouts (magicdance_amd/cldm.py::adapt_clip_keys)."""
+import pytest
+import torch
+
+from magicdance_amd import clip
+from magicdance_amd.cldm import adapt_clip_keys
+
+TINY = dict(num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
+
+
+def test_empty_prompt_tokenizer_matches_clip_convention():
+    ids = clip.EmptyPromptTokenizer()(["", ""], max_length=77)["input_ids"]
+    assert ids.shape == (2, 77) and ids[0, 0] == 49406 and bool((ids[:, 1:] == 49407).all())   # <|startoftext|>, then <|endoftext|> padding
+    with pytest.raises(RuntimeError, match="vocabulary"):
+        clip.EmptyPromptTokenizer()(["a person dancing"])
+
+
+def test_embedder_builds_offline_and_caches_the_empty_prompt():
+    e = clip.FrozenCLIPEmbedder(device="cpu", text_config=TINY)
+    assert e.offline, "the build image has no Hugging Face cache: the fallback tokenizer must be selected"
+    cfg = e.transformer.config
+    assert (cfg.hidden_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.hidden_act) == (768, 49408, 77, "quick_gelu")
+    z = e.encode([""])
+    assert z.shape == (1, 77, 768) and bool(torch.isfinite(z).all())
+    ids = e.tokenizer([""], max_length=77)["input_ids"]
+    want = e.transformer(input_ids=ids).last_hidden_state
+    assert torch.allclose(z, want, atol=1e-6)
+    calls = []
+    orig = e._encode_ids
+    e._encode_ids = lambda i: (calls.append(1), orig(i))[1]
+    z3 = e.encode([""] * 3)                      # served from the cache, repeated per sample
+    assert not calls and z3.shape == (3, 77, 768) and torch.equal(z3[2], z[0])
+    e.load_state_dict(e.state_dict())            # new weights invalidate the cached embedding
+    assert e._empty is None
+    assert all(not p.requires_grad for p in e.parameters())
+
+
+def test_checkpoint_key_adapter_both_directions():
+    e = clip.FrozenCLIPEmbedder(device="cpu", text_config=TINY)
+    pre = "cond_stage_model.transformer."
+    mine = {pre + k: v for k, v in e.transformer.state_dict().items()}
+    has_level = any(k.startswith(pre + "text_model.") for k in mine)
+    # a checkpoint written with the OTHER layout (and the 4.x position_ids buffer) must map onto this module's keys
+    other = {}
+    for k, v in mine.items():
+        rest = k[len(pre):]
+        other[pre + (rest[len("text_model."):] if has_level else "text_model." + rest)] = v
+    other[pre + ("" if has_level else "text_model.") + "embeddings.position_ids"] = torch.arange(77)[None]
+    other["model.diffusion_model.x"] = torch.zeros(1)
+    out = adapt_clip_keys(other, set(mine.keys()) | {"model.diffusion_model.x"})
+    assert set(out.keys()) == set(mine.keys()) | {"model.diffusion_model.x"}
+    assert all(torch.equal(out[k], mine[k]) for k in mine)
+    # same layout: untouched
+    assert adapt_clip_keys(dict(mine), set(mine.keys())).keys() == mine.keys()
+
+
+def test_model_loads_a_checkpoint_with_the_other_clip_layout():
+    """ControlLDMReferenceOnlyPose.load_state_dict (strict) on a checkpoint whose cond_stage_model.* keys use the other
+    transformers layout + position_ids, as model_state-*.th files written under transformers 4.22 do (environment.yml)."""
+    from tests import helpers as H
+    model = H.build_hip_model(64, 2, seed=0, device="cpu", image_size=8, tiny_clip=True)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    pre = "cond_stage_model.transformer."
+    has_level = any(k.startswith(pre + "text_model.") for k in sd)
+    other = {}
+    for k, v in sd.items():
+        if k.startswith(pre):
+            rest = k[len(pre):]
+            k = pre + (rest[len("text_model."):] if has_level else "text_model." + rest)
+        other[k] = v
+    other[pre + ("" if has_level else "text_model.") + "embeddings.position_ids"] = torch.arange(77)[None]
+    model.load_state_dict(other, strict=True)
+    z = model.get_unconditional_conditioning(2)
+    assert z.shape == (2, 77, 768) and torch.equal(z[0], z[1])
+    assert torch.equal(model.get_learned_conditioning([""]), z[:1])

@@ -229,3 +229,30 @@ def test_overlap_sampling_matches_reference_golden(dev):
                             img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
     assert _rel(z.cpu().numpy(), g["z"], "small_b16_overlap z vs golden") <= TOL_Z
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b16_overlap pred_x0 trajectory vs golden") <= TOL_Z
+
+
+def test_text_context_from_the_clip_wrapper(dev):
+    """SURVEY 8f-3 on the GPU: the YAML's text-encoder target (magicdance_amd.clip.FrozenCLIPEmbedder, built from its embedded
+    ViT-L/14 text config, thin test depth) feeds get_learned_conditioning / get_unconditional_conditioning exactly as the entry
+    points call them (test_any_image_pose.py:196-198), and that context drives the HIP sampling path: the result must equal the
+    run that is handed the same [1,77,768] tensor directly."""
+    g = H.load_golden("small_b1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=0, device=dev, image_size=int(g["side"]),
+                              tiny_clip=True)
+    assert next(model.cond_stage_model.parameters()).is_cuda
+    c_cross = model.get_learned_conditioning([""])
+    uc_cross = model.get_unconditional_conditioning(1)
+    assert c_cross.shape == (1, 77, 768) and c_cross.is_cuda and torch.equal(c_cross, uc_cross)
+    ids = model.cond_stage_model.tokenizer([""], max_length=77)["input_ids"].to(dev)
+    want = model.cond_stage_model.transformer(input_ids=ids).last_hidden_state
+    assert torch.allclose(c_cross, want, atol=1e-5)
+    inp = H.case_inputs(g)
+    kw = dict(batch_size=1, ddim=True, ddim_steps=2, eta=0.0, unconditional_guidance_scale=7, inpaint=None, x_T=inp["x_T"].to(dev))
+    mk = lambda ctx: ({"c_concat": [inp["pose"].to(dev)], "c_crossattn": [ctx], "image_control": [inp["ref"].to(dev)], "wonoise": True,  # noqa: E731
+                       "overlap_sampling": False},
+                      {"c_concat": [inp["pose"].to(dev)], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False})
+    c, uc = mk(c_cross)
+    z1, _ = model.sample_log(cond=c, unconditional_conditioning=uc, **kw)
+    c2, uc2 = mk(want.clone())
+    z2, _ = model.sample_log(cond=c2, unconditional_conditioning=uc2, **kw)
+    assert bool(torch.isfinite(z1).all()) and _rel(z1.cpu().numpy(), z2.cpu().numpy(), "clip-wrapper context vs direct tensor") <= 1e-5

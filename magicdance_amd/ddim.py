@@ -246,6 +246,7 @@ class FusedStepRunner:
         self.bank_events = None
         self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
         self.table_stream = torch.cuda.Stream(device=model.device)      # the table pass overlaps the first steps of the loop
+        self.fuse_pose = os.environ.get("MD_FUSE_POSE", "1") != "0"   # zero-conv + residual add as one epilogue
         self.table_chunks = int(os.environ.get("MD_TABLE_CHUNKS", "2"))  # sharded: all-gathers per table (2nd overlaps the loop)
         self.tkey = None
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
@@ -318,6 +319,18 @@ class FusedStepRunner:
         self.ts_table.copy_(torch.from_numpy(np.repeat(steps[:, None], self.ts_table.shape[1], 1).copy()))
         self.coef_table.copy_(torch.from_numpy(coef))
         self.counter.zero_()
+        # Time-embedding tables: timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers depend on the step only, not on
+        # x or the frame: computed here for all S steps at once (same kernels, rows = steps), so that a step reads ONE row per
+        # network (md_select_row_f32) instead of running 4 dependent launches per network at the head of its critical path.
+        arena = unet.arena
+        arena.reset()
+        self.emb_table_unet = unet.time_embedding(self.ts_table[:, 0].contiguous(), S).clone()
+        arena.reset()
+        self.emb_table_pose = pose_e.time_embedding(self.ts_table[:, 0].contiguous(), S).clone()
+        if getattr(self, "emb_cur_unet", None) is None or self.emb_cur_unet.shape[1] != self.emb_table_unet.shape[1]:
+            self.emb_cur_unet = torch.empty((1, self.emb_table_unet.shape[1]), dtype=F32, device=dev)
+            self.emb_cur_pose = torch.empty((1, self.emb_table_pose.shape[1]), dtype=F32, device=dev)
+            self._drop_graph()
 
     def _drop_graph(self):
         if self.graph is not None:
@@ -487,6 +500,8 @@ class FusedStepRunner:
         b = self.b
         ops.select_row_f32(self.ts_table, self.counter, 0, self.t_cur, 2 * b, self.S)
         ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5, self.S)
+        ops.select_row_f32(self.emb_table_unet, self.counter, 0, self.emb_cur_unet, self.emb_cur_unet.shape[1], self.S)
+        ops.select_row_f32(self.emb_table_pose, self.counter, 0, self.emb_cur_pose, self.emb_cur_pose.shape[1], self.S)
         arena = unet.arena
         arena.reset()
         main = torch.cuda.current_stream()
@@ -517,23 +532,39 @@ class FusedStepRunner:
                     app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app, bank_out=banks)
                     app._bank_events = None
                 unet._bank_events = self.bank_events
-            s_pose.wait_stream(main)
-            with torch.cuda.stream(s_pose):
-                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
-            unet._pose_ready = s_pose
-            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                            only_mid_control=model.only_mid_control)
+            if self.fuse_pose:
+                # pose ControlNet on its own stream from the START of the step (it only needs x, the hint features and the time
+                # embedding), its zero-convs adding into the UNet's skips / middle output in place as soon as the UNet's down path
+                # no longer reads them; host order: UNet down path, pose net, UNet up path.
+                ev_start = torch.cuda.Event()
+                ev_start.record(main)
+
+                def pose_fuse(targets, events, nread, only_mid):
+                    s_pose.wait_event(ev_start)
+                    with torch.cuda.stream(s_pose):
+                        pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose,
+                                    fuse=(targets, events, nread, only_mid))
+                    main.wait_stream(s_pose)
+                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, nread=b,
+                                only_mid_control=model.only_mid_control, emb=self.emb_cur_unet, pose_fuse=pose_fuse)
+            else:
+                s_pose.wait_stream(main)
+                with torch.cuda.stream(s_pose):
+                    pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
+                unet._pose_ready = s_pose
+                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                                only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
+                main.wait_stream(s_pose)
             unet._bank_events, unet._pose_ready = None, None
             if not self.table_mode:
                 main.wait_stream(s_app)   # join (the appearance stream ends at its last bank write, already consumed)
-            main.wait_stream(s_pose)
             eps_c, eps_u = eps[:b], eps[b:]
         elif self.overlap == 0:
             banks = self.bank_cur_kv if self.table_mode else \
                 app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
-            pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
+            pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
             eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                            only_mid_control=model.only_mid_control)
+                            only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
             eps_c, eps_u = eps[:b], eps[b:]
         else:
             s_app, s_pose, s_uc = self.side

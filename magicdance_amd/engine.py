@@ -308,7 +308,10 @@ class NetEngine:
         nout = n // 2 if act == MD_ACT_GEGLU else n
         if out is None:
             out = self.arena.alloc((x.b, hout * wout, nout), F32 if out_f32 else F16)
-        out_lo = self.arena.alloc((x.b, hout * wout, nout), F16) if (lo and _RES_LO and not out_f32) else None
+        if isinstance(lo, torch.Tensor):   # explicit second-term buffer (in-place residual epilogue)
+            out_lo = lo
+        else:
+            out_lo = self.arena.alloc((x.b, hout * wout, nout), F16) if (lo and _RES_LO and not out_f32) else None
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
@@ -411,7 +414,8 @@ class NetEngine:
     # ------------------------------------------------------------------ blocks
     def resblock(self, r, x, emb, x1=None):
         h = self.gn(x, r["gn1"], x1=x1, silu=True)
-        h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total)
+        # emb: one row per sample, or ONE row shared by the whole batch (all samples of a DDIM step share the timestep)
+        h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total if emb.shape[0] > 1 else 0)
         h = self.gn(h, r["gn2"], silu=True)
         if "skip_w" in r:
             skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"], lo=True)
@@ -581,41 +585,74 @@ class NetEngine:
                 break  # nothing after the last bank write influences any output (the net returns [])
         return banks
 
-    def pose(self, x, hint_feat, t_dev, ctx_kv):
-        """ControlNet.forward (cldm.py:736-757): 13 zero-conv outputs as Acts."""
+    def pose(self, x, hint_feat, t_dev, ctx_kv, emb=None, fuse=None):
+        """ControlNet.forward (cldm.py:736-757): 13 zero-conv outputs as Acts.  ``emb``: precomputed time_embedding output
+        (fp32 [1 or B, emb_total]; the fused step picks it from a per-schedule table instead of running the MLP every step)."""
         assert self.kind == "pose"
-        emb = self.time_embedding(t_dev, x.shape[0])
+        if emb is None:
+            emb = self.time_embedding(t_dev, x.shape[0])
         outs, ctx_idx = [], [0]
+
+        def zero_conv(i, h, z):
+            """zero-conv i (cldm.py:733-734, 664, 689, 730).  Fused form: its epilogue adds the UNet tensor the
+            residual belongs to -- skip i of the input path, or the middle-block output -- and writes the sum IN PLACE, so that
+            ``hs.pop() + pose.pop()`` / ``h += pose.pop()`` (cldm.py:93-95,102-104) are no launches of their own.  The UNet tensor
+            may be overwritten only once every reader on the UNet's down path is done with it: the event of the FOLLOWING block."""
+            if fuse is None:
+                outs.append(self.conv(h, z["w"], h.c, k=1, bias=z["b"]))
+                return
+            targets, events, nread, only_mid = fuse
+            if only_mid and i < len(targets) - 1:
+                return                                           # cldm.py:98-100: only the middle residual is used
+            tgt = targets[i].head(nread)
+            assert tgt.b == h.b and tgt.hw == h.hw and tgt.c == h.c
+            torch.cuda.current_stream().wait_event(events[i])
+            self.conv(h, z["w"], h.c, k=1, bias=z["b"], res=tgt, out=tgt.t, lo=tgt.lo if tgt.lo is not None else False)
+
         h = self.stem_input(x)
         for i, blk in enumerate(self.input_blocks):
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
             if i == 0:
                 n = h.b * h.hw * h.c
                 ops.add_f16(h.t, hint_feat.t, h.t, n, hint_feat.b * hint_feat.hw * hint_feat.c)  # h += guided_hint
-            z = self.zero_convs[i]
-            outs.append(self.conv(h, z["w"], h.c, k=1, bias=z["b"]))
+            zero_conv(i, h, self.zero_convs[i])
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
-        outs.append(self.conv(h, self.mid_out["w"], h.c, k=1, bias=self.mid_out["b"]))
+        zero_conv(len(self.input_blocks), h, self.mid_out)
         return outs
 
-    def unet(self, x, t_dev, ctx_kv, banks=None, pose=None, nread=0, only_mid_control=False, eps_out=None):
+    def unet(self, x, t_dev, ctx_kv, banks=None, pose=None, nread=0, only_mid_control=False, eps_out=None, emb=None,
+             pose_fuse=None):
         """ControlledUnetModelAttnPose.forward (cldm.py:59-112) on a batch whose first ``nread`` samples take the
         'read' branch (:86-107: bank attention + pose residuals) and whose remaining samples take the 'uc' branch
         (:70-84: plain UNet) -- both branches share every weight, so they run as one batch.
         Returns eps as NHWC fp32 [B, H*W, 4]."""
         assert self.kind == "unet"
         b = sum(int(xi.shape[0]) for xi in x) if isinstance(x, (list, tuple)) else x.shape[0]
-        emb = self.time_embedding(t_dev, b)
+        if emb is None:
+            emb = self.time_embedding(t_dev, b)
         use_bank_in = nread > 0 and banks is not None and len(banks) > 0
         use_bank = use_bank_in and not only_mid_control                            # cldm.py:98-106
         mode = "read"
         hs, ctx_idx, bank_idx = [], [0], [0]
         pose = None if pose is None else list(pose)
         h = self.stem_input(x)
+        evs = [] if pose_fuse is not None else None
         for blk in self.input_blocks:
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
             hs.append(h)
+            if evs is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                evs.append(ev)
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
+        if pose_fuse is not None:
+            # ``pose_fuse(targets, events, nread, only_mid_control)`` runs the pose ControlNet (on its own stream) with the residual
+            # adds fused into its zero-convs: target i = skip i (may be overwritten once input block i + 1 -- the middle block for the
+            # last skip -- is done), target 12 = the middle-block output; it returns after joining that stream into this one.
+            ev_mid = torch.cuda.Event()
+            ev_mid.record(torch.cuda.current_stream())
+            pose_fuse(hs + [h], evs[1:] + [ev_mid, ev_mid], nread, only_mid_control or not use_bank)
+            pose = None
         if self._pose_ready is not None:
             torch.cuda.current_stream().wait_stream(self._pose_ready)
         if nread > 0 and pose is not None:

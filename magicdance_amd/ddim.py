@@ -246,7 +246,10 @@ class FusedStepRunner:
         self.bank_events = None
         self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
         self.table_stream = torch.cuda.Stream(device=model.device)      # the table pass overlaps the first steps of the loop
-        self.fuse_pose = os.environ.get("MD_FUSE_POSE", "1") != "0"   # zero-conv + residual add as one epilogue
+        # zero-conv + residual add as one in-place epilogue.  Built and measured: 13 launches fewer per step but SLOWER
+        # (2.48 vs 2.55 frames/s at configs[1]): a zero-conv may overwrite a skip only after the UNet's next block has read it, so the
+        # pose stream is throttled to the UNet's pace and its tail lands on the critical path.  Off by default (MD_FUSE_POSE=1 enables).
+        self.fuse_pose = os.environ.get("MD_FUSE_POSE", "0") == "1"
         self.table_chunks = int(os.environ.get("MD_TABLE_CHUNKS", "2"))  # sharded: all-gathers per table (2nd overlaps the loop)
         self.tkey = None
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
@@ -322,15 +325,17 @@ class FusedStepRunner:
         # Time-embedding tables: timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers depend on the step only, not on
         # x or the frame: computed here for all S steps at once (same kernels, rows = steps), so that a step reads ONE row per
         # network (md_select_row_f32) instead of running 4 dependent launches per network at the head of its critical path.
+        # (the tables and the current-row buffers are PERSISTENT: the captured step graph holds their addresses)
         arena = unet.arena
-        arena.reset()
-        self.emb_table_unet = unet.time_embedding(self.ts_table[:, 0].contiguous(), S).clone()
-        arena.reset()
-        self.emb_table_pose = pose_e.time_embedding(self.ts_table[:, 0].contiguous(), S).clone()
-        if getattr(self, "emb_cur_unet", None) is None or self.emb_cur_unet.shape[1] != self.emb_table_unet.shape[1]:
-            self.emb_cur_unet = torch.empty((1, self.emb_table_unet.shape[1]), dtype=F32, device=dev)
-            self.emb_cur_pose = torch.empty((1, self.emb_table_pose.shape[1]), dtype=F32, device=dev)
-            self._drop_graph()
+        for name, eng in (("unet", unet), ("pose", pose_e)):
+            arena.reset()
+            tab = eng.time_embedding(self.ts_table[:, 0].contiguous(), S)
+            old = getattr(self, "emb_table_" + name, None)
+            if old is None or old.shape != tab.shape:
+                setattr(self, "emb_table_" + name, torch.empty_like(tab))
+                setattr(self, "emb_cur_" + name, torch.empty((1, tab.shape[1]), dtype=F32, device=dev))
+                self._drop_graph()
+            getattr(self, "emb_table_" + name).copy_(tab)
 
     def _drop_graph(self):
         if self.graph is not None:

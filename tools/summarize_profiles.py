@@ -25,7 +25,7 @@ if os.path.exists(ks):
     ig_calls = sum(int(r["Calls"]) for r in ig)
     execs = sum(int(r["Calls"]) for r in rows if "ddim_update" in r["Name"])
     frames = execs / DDIM_STEPS
-    lines = ["# rocprofv3 --kernel-trace --stats : python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline (configs[1]: 1 frame, "
+    lines = ["# rocprofv3 --kernel-trace --stats : python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra (configs[1]: 1 frame, "
              "reference-KV table pass + 50 DDIM steps + first-stage decode; includes the graph warm-up pass and the capture run)",
              f"# total kernel time {tot / 1e6:.1f} ms over {execs} DDIM-step executions ({frames:.2f} frames) = {tot / 1e6 / frames:.1f} ms/frame, "
              f"{tot / 1e6 / execs:.2f} ms per DDIM step incl. the per-frame table pass and decode (profiled run, kernels serialised by the tracer)",
@@ -55,7 +55,7 @@ for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     kb = sum(v[1] for v in ig.values())
     out[f"igemm_{key}_KB_per_launch_raw"] = kb / max(n, 1)
     out[f"igemm_{key}_launches"] = n
-    lines = [f"# rocprofv3 --pmc {key} : python bench.py --steps 1 --warmup 0 --ddim-steps 4 ; raw counter (KB) per kernel",
+    lines = [f"# rocprofv3 --pmc {key} : python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extra (the benchmarked 50-step batch: table pass + graph warm-up/capture + 50 steps + decode); raw counter (KB) per kernel",
              "# columns: launches, total_KB, avg_KB_per_launch, kernel"]
     for k, (c, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         lines.append(f"{c:8d} {v:14.1f} {v / c:12.1f}  {k}")

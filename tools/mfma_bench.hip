@@ -50,6 +50,53 @@ __global__ __launch_bounds__(256) void mfma_loop(int iters, float* out) {
   if (s[0] + s[1] + s[2] + s[3] == 12345.f) out[0] = s[0];
 }
 
+// 32x32x16 f16 chains with NACC independent accumulators per wave, operands in registers: the shape the guide's 2.38-2.50 PFLOP/s
+// ceiling was measured with (MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA").  Separates what the matrix pipe can sustain from what
+// the 16x16x32 loops above reach.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma32_loop(int iters, float* out) {
+  const int lane = threadIdx.x & 63;
+  h8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (_Float16)(0.001f * ((lane + e) & 7));
+    b[e] = (_Float16)(0.002f * ((lane * 3 + e) & 7));
+  }
+  f16v acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.f) out[0] = s;
+}
+
+template <int NACC>
+void run32(int blocks_per_cu, float* out) {
+  const int iters = 2000, blocks = 256 * blocks_per_cu;
+  auto k = mfma32_loop<NACC>;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, 10, out);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, iters, out);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 * iters * 8.0 * NACC * 32768.0;
+  printf("v_mfma_f32_32x32x16_f16, %d independent accumulators/wave, blocks/CU=%d (waves/SIMD=%d): %7.1f TFLOP/s\n", NACC, blocks_per_cu,
+         blocks_per_cu, flops / (ms * 1e-3) / 1e12);
+}
+
 template <int MODE>
 void run(int blocks_per_cu, float* out, const char* label) {
   const int iters = 4000, blocks = 256 * blocks_per_cu;
@@ -91,6 +138,11 @@ int main() {
   for (int b : {1, 2}) {
     run<0>(b, out, "MFMA only (regs)");
     run<1>(b, out, "8 ds_read_b128 + 16 MFMA per k-step");
+  }
+  for (int b : {1, 2}) {
+    run32<1>(b, out);
+    run32<2>(b, out);
+    run32<4>(b, out);
   }
   return 0;
 }

@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--sequence", type=int, default=0,
                     help="non-default workload: a pose sequence of this many frames per GPU sharing one reference image "
                          "(bank table computed once per sequence), sampled in batches of --frames-per-gpu")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="BASELINE configs[4] path: K / V^T / bank table as OCP e4m3, attention contractions on the fp8 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="stop at the latents (skip the first-stage decode)")
@@ -146,7 +148,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from magicdance_amd import synthetic, ops
-    from magicdance_amd import parallel
+    from magicdance_amd import parallel, engine
+    if args.fp8_attention:
+        engine.ATTN_FP8 = True   # read when the engines pack their weights / allocate their K / V^T buffers
     model = build_model(dev, args.size)
     fpg = args.frames_per_gpu if args.frames_per_gpu else (1 if world == 1 else 8)
     cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get((fpg, world), "configs[3]" if (fpg == 8 and world > 1) else "custom")
@@ -185,7 +189,7 @@ def main():
     frames = args.steps * (args.sequence if args.sequence else fpg) * world
     out = {"metric": "512x512 frames/sec @ 50 DDIM steps", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16 (attention operands e4m3)" if args.fp8_attention else "f16", "data": "synthetic",
            "ms_per_ddim_step": 1e3 * dt / args.steps / args.ddim_steps,
            "config": {"workload": (f"sequence of {args.sequence} frames/GPU sharing one reference (bank table once per sequence), "
                                    f"batches of {fpg}, " if args.sequence else f"{cfg_name}: {fpg} frame(s)/GPU as one batch, ") +

@@ -100,6 +100,13 @@ typedef struct {
    * scales q.k^T; here q itself, while still fp32).  col_scale_end = 0 disables; multiple of 4. */
   float col_scale;
   int32_t col_scale_end;
+  /* fp8 attention operands (BASELINE configs[4]): columns [k8_begin, k8_end) (multiples of 4, below n_tr_begin) are written as
+   * OCP e4m3 bytes to k8[m * ld_k8 + (n - k8_begin)] instead of to `out`; vt_fp8 = 1 stores the transposed columns (out_t, ld_t in
+   * bytes) as e4m3 bytes.  The K / V^T halves of the fused to_q|k|v projection and of the bank projection feed md_attention
+   * kv_fp8 this way.  k8 = NULL / vt_fp8 = 0: fp16 as before. */
+  void* k8;
+  int32_t k8_begin, k8_end, ld_k8;
+  int32_t vt_fp8;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
@@ -130,6 +137,9 @@ typedef struct {
   int32_t q_prescaled;     /* ABI v2.  1: q already carries scale * log2(e) -- written that way by the projection GEMM (md_igemm
                             * col_scale), i.e. folded in before the fp16 rounding of q -- so q.k is the logit in the exp2 domain and
                             * `scale` is ignored; 0: the kernel applies scale * log2(e) itself */
+  int32_t kv_fp8;          /* ABI v2.  1: k0 / vt0 / k1 / vt1 hold OCP e4m3 bytes (written by md_igemm k8 / vt_fp8; leading dimensions and
+                            * batch strides in bytes, multiples of 16); q stays fp16 and is converted in registers, P is converted to
+                            * e4m3, both contractions run on the fp8 MFMA with fp32 accumulation (BASELINE configs[4]). */
 } md_attention_params;
 
 int md_attention(const md_attention_params* p, void* stream);

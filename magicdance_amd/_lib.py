@@ -25,7 +25,8 @@ class IgemmParams(C.Structure):
         ("n_tr_begin", C.c_int32), ("ld_t", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("force_cfg", C.c_int32), ("force_splitk", C.c_int32), ("ln_s1", C.c_void_p), ("ln_s0", C.c_void_p),
         ("ln_eps", C.c_float), ("asym_pad", C.c_int32), ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
-        ("col_scale", C.c_float), ("col_scale_end", C.c_int32),
+        ("col_scale", C.c_float), ("col_scale_end", C.c_int32), ("k8", C.c_void_p), ("k8_begin", C.c_int32),
+        ("k8_end", C.c_int32), ("ld_k8", C.c_int32), ("vt_fp8", C.c_int32),
     ]
 
 
@@ -39,7 +40,7 @@ class AttentionParams(C.Structure):
         ("n1_batches", C.c_int32),
         ("out", C.c_void_p), ("out_batch_stride", C.c_int64), ("ld_out", C.c_int32),
         ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("d", C.c_int32), ("scale", C.c_float),
-        ("q_prescaled", C.c_int32),
+        ("q_prescaled", C.c_int32), ("kv_fp8", C.c_int32),
     ]
 
 

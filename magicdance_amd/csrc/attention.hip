@@ -40,6 +40,7 @@ struct AttnArgs {
   int batch, heads, nq;
   float c;  // scale * log2(e)
   int q_prescaled;  // q already carries scale * log2(e) (projection GEMM epilogue): scores come out in the exp2 domain
+  int kv_fp8;       // K / V^T (both segments) are e4m3 bytes
 };
 
 template <int D, int QF>
@@ -1030,6 +1031,235 @@ int launch_v2(const AttnArgs& g, hipStream_t s) {
   return MD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp8 variant (BASELINE configs[4], "fp8 MFMA attention path"): K and V^T are OCP e4m3 in memory (written that way by the
+// projection GEMM's epilogue, md_igemm k8 / vt_fp8), Q (fp16 in memory) and P are converted to e4m3 in registers, both
+// contractions run on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation; softmax statistics stay fp32.  Half the K / V^T bytes
+// per tile (the MFMA rate of the non-scaled fp8 form equals the fp16 rate on gfx950, and the kernel is VALU-bound on its softmax:
+// this path is about operand bytes and about exercising the fp8 matrix path, not about speed).  Structure = v2's 2-stage LDS-DMA
+// loop.  Tiles: K 64 rows x DKB bytes (DKB = 64 / 128 / 192 >= d, 16-byte chunks), V^T DV rows x 64 bytes; a lane's MFMA operand
+// is 8 consecutive bytes (ds_read_b64).  Swizzles (on 16-byte chunks, applied to the DMA source): K chunk ^ ((row >> 3) & 3),
+// V^T chunk ^ ((row >> 2) & 3): the 32 lanes of one ds_read_b64 pass then cover 32 distinct 8-byte slots of the 256-byte bank
+// window.  K rows are permuted as in v2 so that the 8 kv a lane feeds to the PV MFMA are 8 consecutive bytes of a V^T row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel_fp8(const AttnArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DK = (D + 31) / 32 * 32;           // contraction length (elements = bytes), zero padded
+  constexpr int KSTEPS = DK / 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int DV = DF * 16;
+  constexpr int KC = (DK + 63) / 64 * 4;           // 16-byte chunks per K row in LDS (row = 64 / 128 / 192 bytes)
+  constexpr int KROWB = KC * 16;
+  constexpr int KJ = (64 * KC + 255) / 256;        // K DMA instructions per thread per tile
+  constexpr int VJ = (DV * 4 + 255) / 256;         // V^T: DV rows x 4 chunks
+  constexpr int KBYTES = KJ * 4096, VBYTES = VJ * 4096;
+  constexpr int STAGE = KBYTES + VBYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  typedef const unsigned char u8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qbase = blockIdx.x * 64 + wave * 16;
+
+  // Q fragment (B operand of S^T = K Q^T): lane holds Q[q = lr][d = ks*32 + lg*8 .. +8] as 8 e4m3 bytes, scale folded in
+  long qf[KSTEPS];
+  {
+    const int row = qbase + lr;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int d = ks * 32 + lg * 8;
+      if (row < g.nq && d < D) v = *reinterpret_cast<const h8*>(g.q + b * g.q_bs + (long long)row * g.ld_q + h * D + d);
+      const float sc = g.q_prescaled ? 1.0f : g.c;
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[0] * sc, (float)v[1] * sc, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[2] * sc, (float)v[3] * sc, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[4] * sc, (float)v[5] * sc, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[6] * sc, (float)v[7] * sc, hi, true);
+      qf[ks] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+  }
+
+  const int t0 = (g.n0 + 63) >> 6;
+  const int t1 = (g.k1 != nullptr && b < g.n1_batches) ? ((g.n1 + 63) >> 6) : 0;
+  const int ntiles = t0 + t1;
+  u8* k0b = reinterpret_cast<u8*>(g.k0) + b * g.k0_bs;
+  u8* v0b = reinterpret_cast<u8*>(g.vt0) + b * g.vt0_bs;
+  u8* k1b = g.k1 ? reinterpret_cast<u8*>(g.k1) + b * g.k1_bs : k0b;
+  u8* v1b = g.vt1 ? reinterpret_cast<u8*>(g.vt1) + b * g.vt1_bs : v0b;
+  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(k0b), 0, g.n0 * g.ld_k0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(v0b), 0, g.heads * D * g.ld_vt0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(k1b), 0, g.k1 ? g.n1 * g.ld_k1 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(v1b), 0, g.vt1 ? g.heads * D * g.ld_vt1 : 0, 0x00020000);
+  unsigned ko0[KJ], ko1[KJ], vo0[VJ], vo1[VJ];
+  int krow_[KJ], vkv_[VJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const int i = j * 256 + tid;                  // LDS chunk index of this lane's DMA slot
+    const int r = i / KC, pos = i % KC;
+    const int sc = pos ^ ((r >> 3) & 3);          // source chunk held at this position (KC is a multiple of 4)
+    // a chunk is fetched whole (16 bytes): the last one of a head may run into the next head's bytes -- multiplied by Q's zero
+    // padding -- or past the end of the tensor (hardware returns zeros)
+    const bool ok = i < 64 * KC && sc * 16 < D;
+    krow_[j] = r;
+    ko0[j] = ok ? (unsigned)(r * g.ld_k0 + h * D + sc * 16) : OOB;
+    ko1[j] = ok ? (unsigned)(r * g.ld_k1 + h * D + sc * 16) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) {
+    const int i = j * 256 + tid;
+    const int r = i >> 2, pos = i & 3;
+    const int sc = pos ^ ((r >> 2) & 3);
+    const bool ok = r < D;
+    vkv_[j] = sc * 16;
+    vo0[j] = ok ? (unsigned)((h * D + r) * g.ld_vt0 + sc * 16) : OOB;
+    vo1[j] = ok ? (unsigned)((h * D + r) * g.ld_vt1 + sc * 16) : OOB;
+  }
+
+  auto issue_tile = [&](int t, int stage) {
+    char* Ks = smem + stage * STAGE;
+    char* Vs = Ks + KBYTES;
+    const bool s1 = t >= t0;
+    const int kv0 = (s1 ? t - t0 : t) << 6;
+    const int nseg = s1 ? g.n1 : g.n0;
+    const unsigned ksoff = (unsigned)(kv0 * (s1 ? g.ld_k1 : g.ld_k0)), vsoff = (unsigned)kv0;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const unsigned off = (kv0 + krow_[j] < nseg) ? (s1 ? ko1[j] : ko0[j]) : OOB;
+      if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk1, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16, off, ksoff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rk0, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16, off, ksoff, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      // a 16-byte chunk of kv may straddle the end of the segment: bytes past it belong to pad columns of V^T (zeros, ld is
+      // padded to 16) or are masked through P = 0
+      const unsigned off = (kv0 + vkv_[j] < nseg) ? (s1 ? vo1[j] : vo0[j]) : OOB;
+      if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv1, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16, off, vsoff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rv0, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16, off, vsoff, 0, 0);
+    }
+  };
+
+  f4 o[DF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  auto compute_tile = [&](int t, int stage) {
+    const char* Ks = smem + stage * STAGE;
+    const char* Vs = Ks + KBYTES;
+    const bool s1 = t >= t0;
+    const int kv0 = (s1 ? t - t0 : t) << 6;
+    const int nseg = s1 ? g.n1 : g.n0;
+    f4 st[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      st[kf] = f4{0.f, 0.f, 0.f, 0.f};
+      const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int slot = ks * 4 + lg;                                   // 8-byte slot of the row
+        const long kfrag = *reinterpret_cast<const long*>(Ks + row * KROWB + ((((slot >> 1) ^ ((row >> 3) & 3)) << 4) | ((slot & 1) << 3)));
+        st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kfrag, qf[ks], st[kf], 0, 0, 0);
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane(kv0 + 64 - nseg) > 0) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + 32 * (kf >> 1) + 8 * lg + 4 * (kf & 1) + r >= nseg) st[kf][r] = -INFINITY;
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
+    const float alpha = grew ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
+    m_run = m_new;
+    float ps = 0.f;
+    long pf[2];
+#pragma unroll
+    for (int pk = 0; pk < 2; ++pk) {
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p[e] = __builtin_amdgcn_exp2f(st[2 * pk + (e >> 2)][e & 3] - m_new);
+        ps += p[e];
+      }
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[4], p[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[6], p[7], hi, true);
+      pf[pk] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+    if (grew) {
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DF; ++i) o[i] *= alpha;
+    }
+    l_run += ps;
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int pk = 0; pk < 2; ++pk) {
+        const int slot = pk * 4 + lg;
+        const long vfrag = *reinterpret_cast<const long*>(Vs + row * 64 + ((((slot >> 1) ^ ((row >> 2) & 3)) << 4) | ((slot & 1) << 3)));
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vfrag, pf[pk], o[i], 0, 0, 0);
+      }
+    }
+  };
+
+  issue_tile(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+    compute_tile(t, t & 1);
+  }
+
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int row = qbase + lr;
+  if (row < g.nq) {
+    half_t* op = g.out + b * g.out_bs + (long long)row * g.ld_out + h * D;
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      const int d = i * 16 + lg * 4;
+      if (d < D) {
+        h4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[i][r] * inv);
+        *reinterpret_cast<h4*>(op + d) = ov;
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int D>
+int launch_fp8(const AttnArgs& g, hipStream_t s) {
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr int DF = (D + 15) / 16;
+  constexpr int KC = (DK + 63) / 64 * 4;
+  constexpr int KJ = (64 * KC + 255) / 256, VJ = (DF * 16 * 4 + 255) / 256;
+  constexpr size_t lds = (size_t)2 * (KJ + VJ) * 4096;
+  static_assert(lds <= 65536, "fp8 attention tiles fit the default dynamic LDS limit");
+  dim3 grid((g.nq + 63) / 64, g.heads, g.batch);
+  hipLaunchKernelGGL((attn_kernel_fp8<D>), grid, dim3(256), lds, s, g);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 template <int D, int QF>
 int launch(const AttnArgs& g, hipStream_t s) {
   constexpr int BQ = 64 * QF;
@@ -1078,6 +1308,7 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   g.heads = p->heads;
   g.nq = p->nq;
   g.q_prescaled = p->q_prescaled ? 1 : 0;
+  g.kv_fp8 = p->kv_fp8 ? 1 : 0;
   g.c = g.q_prescaled ? 1.0f : p->scale * 1.4426950408889634f;   // prescaled q: the scores already are log2-domain logits
   hipStream_t s = (hipStream_t)stream;
   const double nkv = (double)p->n0 + (double)g.n1 * ((double)(g.n1_batches < p->batch ? g.n1_batches : p->batch) / p->batch);
@@ -1088,6 +1319,20 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
                      2.0 * p->batch * p->heads * p->d * (2.0 * p->nq + 2.0 * nkv), tag);
   // 128-row query blocks (QF 2) halve the K/V traffic per MFMA but need >= ~2 workgroups per CU to hide the per-tile
   // latency chain; below that 64-row blocks win (measured: d=80 72->49 us, d=40 B=1 104->94 us, d=40 B=2 unchanged)
+  if (p->kv_fp8) {
+    // e4m3 K / V^T: byte tensors, 16-byte aligned rows (the DMA moves 16-byte chunks)
+    if ((p->ld_k0 & 15) || (p->ld_vt0 & 15) || (p->k1 && ((p->ld_k1 & 15) || (p->ld_vt1 & 15)))) return MD_ERR_BAD_ARG;
+    if ((p->k0_batch_stride & 15) || (p->vt0_batch_stride & 15) || (p->k1_batch_stride & 15) || (p->vt1_batch_stride & 15)) return MD_ERR_BAD_ARG;
+    switch (p->d) {
+      case 40: return launch_fp8<40>(g, s);
+      case 80: return launch_fp8<80>(g, s);
+      case 160: return launch_fp8<160>(g, s);
+      case 32: return launch_fp8<32>(g, s);
+      case 64: return launch_fp8<64>(g, s);
+      case 128: return launch_fp8<128>(g, s);
+      default: return MD_ERR_UNSUPPORTED;
+    }
+  }
   static const int qf_force = [] {
     const char* e = getenv("MD_ATTN_QF");
     return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;

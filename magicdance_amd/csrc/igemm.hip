@@ -45,6 +45,9 @@ struct IgemmArgs {
   half_t* out_lo;
   float col_scale;
   int col_scale_end;
+  unsigned char* k8;      // columns [k8_begin, k8_end) go here as e4m3 bytes ([M][ld_k8]) instead of to `out`
+  int k8_begin, k8_end, ld_k8;
+  int vt_fp8;             // the transposed columns (n >= n_tr_begin) are stored as e4m3 bytes
   int ld_out;
   int out_f32;
   half_t* out_t;
@@ -79,9 +82,25 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
     // transposed store (V^T): [b][n - n_tr][tok]
     const int tok = m - b * g.tokens;
     const int ntr = g.N - g.n_tr_begin;
+    if (g.vt_fp8) {   // e4m3 bytes (fp8 attention path)
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+      unsigned char* o8 = reinterpret_cast<unsigned char*>(g.out_t) + ((long long)b * ntr + (n - g.n_tr_begin)) * g.ld_t + tok;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o8[(long long)i * g.ld_t] = (unsigned char)((unsigned)w >> (8 * i));
+      return;
+    }
     half_t* o = g.out_t + ((long long)b * ntr + (n - g.n_tr_begin)) * g.ld_t + tok;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[(long long)i * g.ld_t] = (half_t)v[i];
+    return;
+  }
+  if (g.k8 && n >= g.k8_begin && n < g.k8_end) {   // K columns of a fused q|k|v projection as e4m3 bytes
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    *reinterpret_cast<int*>(g.k8 + (long long)m * g.ld_k8 + (n - g.k8_begin)) = w;
     return;
   }
   if (g.res) {
@@ -125,7 +144,13 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 // the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
 //   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
 //   MFMAs on the landed stage.  Tiles past the end are fetched from the zero page so the outstanding count is constant.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1>
+// M32 = true: v_mfma_f32_32x32x16_f16 fragments (a wave tile is MF32 x NF32 fragments of 32 x 32).  Register-only loops of the
+// 16x16x32 form sustain 1.3-1.6 PFLOP/s on this chip, 32x32x16 chains 2.15-2.23 (profiles/round2_mfma_issue_rate.txt); the
+// operand bytes read from LDS per MFMA are the same (one ds_read_b128 per lane and operand), per flop half.  LDS swizzle:
+// chunk ^ ((row >> 1) & 7) -- a 16-lane ds_read_b128 group of the 32-row fragment read holds rows {0-3, 12-15, 20-27} (or
+// {4-11, 16-19, 28-31}); rows of equal parity share a 128-byte half of the 256-byte bank window, and (row >> 1) & 7 is distinct
+// over each group's same-parity rows, so the reads are conflict-free (row & 7, the 16-row form's swizzle, would be 2-way).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
   constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
@@ -140,6 +165,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   constexpr bool W_TAIL = (BN % 32) != 0;
   static_assert(!W_TAIL || LOADER == 2, "ragged BN is implemented for the buffer loader only");
   static_assert(BM % 32 == 0 && BN % 16 == 0, "tile shape");
+  static_assert(!M32 || (LOADER == 2 && STAGES == 2 && KT == 1 && WTM % 32 == 0 && WTN % 32 == 0), "32x32 fragments: 2-stage buffer loader tiles");
+  constexpr int MF32 = WTM / 32, NF32 = WTN / 32;
+  typedef float f16v __attribute__((ext_vector_type(16)));
   // KT = 64-deep k-tiles per pipeline stage.  KT = 2 (small tiles, 2-stage buffer loader): one vmcnt(0)+barrier round trip
   // fetches two k-tiles -- the k-loop of a small GEMM on cold weights is one HBM round trip per iteration, so twice the
   // bytes per trip halves its length.  LDS addressing is by SLOT = stage * KT + sub-tile.
@@ -172,7 +200,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 
   // ---- loader role: LDS slot (row, lc) for rows lrow + 32 j; fixed global k-chunk gc -------------------------
   const int lc = tid & 7, lrow = tid >> 3;
-  const int gc = lc ^ (lrow & 7);  // row & 7 == lrow & 7 for every row this thread serves
+  // source chunk held at LDS position lc of this thread's rows (lrow + 32 j: the swizzle key is the same for all of them)
+  const int gc = lc ^ (M32 ? ((lrow >> 1) & 7) : (lrow & 7));
   const int ups = g.ups;           // 0 / 1: source coordinate = virtual coordinate >> ups
   // 2-stage buffer loader: the W part of the FIRST k-tile depends on nothing computed below, so its LDS-DMA is issued
   // before the per-row im2col setup (a few hundred VALU): the HBM latency of the layer's cold weights overlaps it
@@ -378,18 +407,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     for (int j = 0; j < WJ; ++j) *reinterpret_cast<h8*>(Ws + (lrow + 32 * j) * 128 + (lc << 4)) = rw[j];
   };
 
-  f4 acc[NF][MF];
+  f4 acc[M32 ? 1 : NF][M32 ? 1 : MF];
+  f16v acc32[M32 ? NF32 : 1][M32 ? MF32 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < NF; ++i)
+    for (int i = 0; i < NF32; ++i)
 #pragma unroll
-    for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < MF32; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int l31 = lane & 31, lh = lane >> 5;   // 32x32 fragments: row / column index and k-half of this lane
 
   // LN: per-lane partial sum / sum of squares of the A rows this lane reads as MFMA operands (row i*16+lr, k-chunks lg and
   // 4+lg of every 64-wide tile = a quarter of K); the four lg lanes are combined after the k-loop.
-  [[maybe_unused]] float ln_sum[MF], ln_sq[MF];
+  constexpr int LNF = M32 ? MF32 : MF;
+  [[maybe_unused]] float ln_sum[LNF], ln_sq[LNF];
   if constexpr (LN) {
 #pragma unroll
-    for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
+    for (int i = 0; i < LNF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
   }
 
   auto compute_tile = [&](int stage) {
@@ -417,6 +458,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       return;
     }
 #endif
+    if constexpr (M32) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {   // four 16-deep k-steps per 64-deep tile; lane half lh holds k = 8 lh .. 8 lh + 7 of a step
+        h8 af[MF32], wf[NF32];
+        const int chunk = ks * 2 + lh;
+#pragma unroll
+        for (int i = 0; i < MF32; ++i) {
+          const int row = wm * WTM + i * 32 + l31;
+          af[i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < NF32; ++i) {
+          const int row = wn * WTN + i * 32 + l31;
+          wf[i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
+        if constexpr (LN) {
+          typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+          const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+          for (int i = 0; i < MF32; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const h2v p = {af[i][2 * e], af[i][2 * e + 1]};
+              ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
+              ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NF32; ++i)
+#pragma unroll
+          for (int j = 0; j < MF32; ++j)
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc32[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       h8 af[MF], wf[NF];
@@ -510,6 +587,68 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
+  if constexpr (M32) {
+    // fragment (i, j): lane holds column m = j*32 + l31 and, in registers 4q .. 4q+3, rows n = i*32 + 8q + 4 lh + (0..3)
+    if constexpr (LN) {
+#pragma unroll
+      for (int j = 0; j < MF32; ++j) {
+        float sm = ln_sum[j], sq = ln_sq[j];
+        sm += __shfl_xor(sm, 32, 64);   // the two lane halves hold the two k-halves of every 16-deep step
+        sq += __shfl_xor(sq, 32, 64);
+        const float mu = sm * g.ln_inv_k;
+        const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_k - mu * mu, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NF32; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = min(n0 + wn * WTN + i * 32 + 8 * q + 4 * lh, g.N - 4);
+            const f4 s1 = *reinterpret_cast<const f4*>(g.ln_s1 + n), s0 = *reinterpret_cast<const f4*>(g.ln_s0 + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc32[i][j][4 * q + e] = rstd * (acc32[i][j][4 * q + e] - mu * s1[e]) + s0[e];
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MF32; ++j) {
+      const int m = m0 + wm * WTM + j * 32 + l31;
+      if (m >= g.M) continue;
+      const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
+#pragma unroll
+      for (int i = 0; i < NF32; ++i) {
+        if (g.act == MD_ACT_GEGLU && g.splitk <= 1) {
+          // packed rows [a0..15 | gate0..15] per 32: registers q = 0, 1 hold a, q = 2, 3 the gates of the same output columns
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int np = n0 + wn * WTN + i * 32 + 8 * q + 4 * lh;
+            if (np + 16 >= g.N) continue;
+            f4 av = {acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
+            f4 gv = {acc32[i][j][4 * q + 8], acc32[i][j][4 * q + 9], acc32[i][j][4 * q + 10], acc32[i][j][4 * q + 11]};
+            if (g.bias) {
+              av += *reinterpret_cast<const f4*>(g.bias + np);
+              gv += *reinterpret_cast<const f4*>(g.bias + np + 16);
+            }
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
+            const int oc = (n0 + wn * WTN + i * 32) / 2 + 8 * q + 4 * lh;
+            *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + oc) = o;
+          }
+          continue;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * lh;
+          if (n >= g.N) continue;
+          const f4 v = {acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
+          if (g.splitk > 1)
+            *reinterpret_cast<f4*>(g.ws + ((long long)kz * g.M + m) * g.N + n) = v;
+          else
+            epi_store4(g, m, b, n, v);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (LN) {
     // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
     // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
@@ -616,9 +755,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 // families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
 //           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
-const float kTileEff[14] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f, 0.70f, 0.60f};
-const int kTileBM[14] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64, 64, 64};
-const int kTileBN[14] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160, 64, 80};
+const float kTileEff[18] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f, 0.70f, 0.60f, 1.0f, 1.0f, 1.0f, 1.0f};
+const int kTileBM[18] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64, 64, 64, 128, 128, 256, 256};
+const int kTileBN[18] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160, 64, 80, 128, 160, 128, 160};
 constexpr int kNumFamilies = 6;
 constexpr int kNumCfgs = 4 * kNumFamilies;
 // configs 24..27: SD-shaped tiles of the buffer loader (2 stages) -- 128x80, 128x160, 64x160, 64x80.  Every channel count of
@@ -626,7 +765,8 @@ constexpr int kNumCfgs = 4 * kNumFamilies;
 // M = 8192, N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
 // configs 28..31: two k-tiles per stage (KT = 2) for 64x64, 64x80, 128x80, 64x160 -- half the HBM round trips in the k-loop
 // of the small cold-weight GEMMs of a 1-frame step; 32, 33: four k-tiles per stage for 64x64, 64x80 (128 / 147 KB of LDS).
-constexpr int kFirstSdCfg = 24, kNumAllCfgs = 34;
+// configs 34..37: 32x32x16-fragment tiles -- 128x128 (2x2 waves), 128x160 (4x1), 256x128 (4x1), 256x160 (4x1)
+constexpr int kFirstSdCfg = 24, kNumAllCfgs = 38;
 struct TileCfg {
   int bm, bn;
   float eff;
@@ -636,15 +776,15 @@ inline TileCfg cfg_of(int c) {
   return TileCfg{kTileBM[t], kTileBN[t], kTileEff[t]};
 }
 // tiles whose per-wave fragment count along N is odd cannot host the GEGLU pairing
-inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28 || c == 32; }
-inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || c >= kFirstSdCfg; }
+inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28 || c == 32 || c >= 34; }
+inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || (c >= kFirstSdCfg && c < 34); }
 // default loader family: MD_IGEMM_LOADER = 0..4
 int g_default_loader = [] {
   const char* e = getenv("MD_IGEMM_LOADER");
   return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
 }();
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1>
+template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 128;
   static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
@@ -652,13 +792,13 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -667,6 +807,12 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
 template <int BM, int BN, int WMv, int WNv, int KT = 1>
 int launch_buf2(const IgemmArgs& g, hipStream_t s) {
   return g.ln_s1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, true, KT>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT>(g, s);
+}
+// 32x32x16-fragment tiles (2-stage buffer loader)
+template <int BM, int BN, int WMv, int WNv>
+int launch_m32(const IgemmArgs& g, hipStream_t s) {
+  if (g.ln_s1) return MD_ERR_UNSUPPORTED;   // the folded-LayerNorm GEMMs are small-M: they stay on the 16x16 tiles
+  return launch_cfg<BM, BN, WMv, WNv, 2, 2, false, 1, true>(g, s);
 }
 
 void fast_div_magic(unsigned d, unsigned* mul, unsigned* sh) {
@@ -691,6 +837,8 @@ int validate(const md_igemm_params* p) {
   if (p->res && (p->ld_res & 3)) return MD_ERR_BAD_ARG;
   if (p->res_lo && !p->res) return MD_ERR_BAD_ARG;
   if (p->out_lo && (p->out_f32 || p->act == MD_ACT_GEGLU)) return MD_ERR_UNSUPPORTED;
+  if (p->k8 && ((p->k8_begin & 3) || (p->k8_end & 3) || (p->ld_k8 & 3) || p->k8_begin < 0 || p->k8_end > p->n_tr_begin || p->act == MD_ACT_GEGLU))
+    return MD_ERR_BAD_ARG;
   if (p->col_scale_end < 0 || (p->col_scale_end & 3) || (p->col_scale_end && p->act == MD_ACT_GEGLU)) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
@@ -813,6 +961,11 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.out_lo = (half_t*)p->out_lo;
   g.col_scale = p->col_scale;
   g.col_scale_end = p->col_scale_end;
+  g.k8 = (unsigned char*)p->k8;
+  g.k8_begin = p->k8_begin;
+  g.k8_end = p->k8_end;
+  g.ld_k8 = p->ld_k8;
+  g.vt_fp8 = p->vt_fp8;
   g.ld_res = p->ld_res;
   g.act = p->act;
   g.out = p->out;
@@ -875,6 +1028,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
     case 31: rc = launch_buf2<64, 160, 2, 2, 2>(g, s); break;
     case 32: rc = launch_buf2<64, 64, 2, 2, 4>(g, s); break;
     case 33: rc = launch_buf2<64, 80, 4, 1, 4>(g, s); break;
+    case 34: rc = launch_m32<128, 128, 2, 2>(g, s); break;
+    case 35: rc = launch_m32<128, 160, 4, 1>(g, s); break;
+    case 36: rc = launch_m32<256, 128, 4, 1>(g, s); break;
+    case 37: rc = launch_m32<256, 160, 4, 1>(g, s); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
     case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
     case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;

@@ -304,7 +304,8 @@ class FusedStepRunner:
             self._allocate(key, b, cch, hh, ww, S, bref, table_mode)
         if table_mode:
             per, nblocks = self.plan_table(S, bref, world)
-            tkey = (cch, hh, ww, S, bref, per, nblocks)
+            from . import engine as _eng
+            tkey = (cch, hh, ww, S, bref, per, nblocks, _eng.ATTN_FP8)
             if tkey != self.tkey:
                 self._allocate_table(tkey, hh, ww, S, bref, per, nblocks)
         self.ref.copy_(ref)
@@ -360,23 +361,28 @@ class FusedStepRunner:
     def _allocate_table(self, tkey, hh, ww, S, bref, per, nblocks):
         """Reference-KV table, layout [row block][segment][per rows][row length]; segment 2e = K of bank entry e
         ([bref, n, c] per row), 2e + 1 = its V^T ([bref, c, ldv] per row, pad columns stay zero)."""
+        from . import engine
         from .engine import BankKV
         from .nets import bank_shapes
         dev = self.model.device
         self._drop_graph()
         self.tkey, self.per, self.nblocks = tkey, per, nblocks
         app = self.model.engines()[0]
+        tdtype = torch.uint8 if engine.ATTN_FP8 else F16      # fp8 attention path: the table holds e4m3 bytes (half the size)
+        u = 16 // (1 if engine.ATTN_FP8 else 2)               # elements per 16-byte unit of md_gather_rows
+        self.table_unit = u
         self.bank_geo, segs, boff, coff = [], [], 0, 0
         for n, c in bank_shapes(app.cfg, (hh, ww)):
-            ldv = (n + 7) & ~7
+            ldv = engine.kv_ld(n)
             lk, lv = bref * n * c, bref * c * ldv
+            assert lk % u == 0 and lv % u == 0
             self.bank_geo.append((boff, boff + per * lk, coff, coff + lk, n, c, ldv))
-            segs += [(boff // 8, lk // 8, coff // 8), ((boff + per * lk) // 8, lv // 8, (coff + lk) // 8)]
+            segs += [(boff // u, lk // u, coff // u), ((boff + per * lk) // u, lv // u, (coff + lk) // u)]
             boff += per * (lk + lv)
             coff += lk + lv
         self.block_elems = boff
-        self.bank_table = torch.zeros((nblocks * boff,), dtype=F16, device=dev)   # zeros: the V^T pad columns stay zero
-        self.bank_cur = torch.zeros((coff,), dtype=F16, device=dev)
+        self.bank_table = torch.zeros((nblocks * boff,), dtype=tdtype, device=dev)   # zeros: the V^T pad columns stay zero
+        self.bank_cur = torch.zeros((coff,), dtype=tdtype, device=dev)
         self.bank_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
         self.bank_seg_max = max(sg[1] for sg in segs)
         self.bank_cur_kv = [BankKV(self.bank_cur[ck:ck + bref * n * c].view(bref, n, c),
@@ -513,7 +519,7 @@ class FusedStepRunner:
         oc = unet.cfg.out_channels
         if self.table_mode:
             ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
-                            self.bank_cur, self.S, self.per, self.block_elems // 8)
+                            self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
         if self.overlap == 3:
             s_app, s_pose, _ = self.side
             if self.table_mode:

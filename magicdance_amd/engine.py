@@ -79,6 +79,16 @@ _FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
 # reference's CPU path) carry the part their fp16 store dropped to the next link, so the chain's rounding does not accumulate
 # with depth (md_igemm res_lo / out_lo).  MD_RES_LO=0 restores the single-term stream (parity / cost A-B).
 _RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
+# fp8 attention path (BASELINE configs[4]): the self / bank attention's K and V^T are written as OCP e4m3 bytes by the projection
+# GEMMs and md_attention runs its contractions on the fp8 MFMA (q and P converted in registers).  Off by default (the fp16 path is
+# the parity path); bench.py --fp8-attention / MD_ATTN_FP8=1 switch it on BEFORE the engines are built.
+ATTN_FP8 = os.environ.get("MD_ATTN_FP8", "0") == "1"
+U8 = torch.uint8
+
+
+def kv_ld(n):
+    """leading dimension (tokens) of a V^T operand: 16-byte rows -- 8 fp16 or 16 e4m3"""
+    return (n + 15) & ~15 if ATTN_FP8 else (n + 7) & ~7
 
 
 def get_arena(device, name=""):
@@ -430,7 +440,7 @@ class NetEngine:
         the value is still fp32), so that md_attention's scores come out of the MFMAs as exp2-domain logits"""
         return float(dh) ** -0.5 * 1.4426950408889634
 
-    def attention(self, q, ld_q, k0, ld_k0, vt0, ld_vt0, n0, b, nq, heads, dh, *, k0_bs, vt0_bs, seg1=None, n1_batches=0):
+    def attention(self, q, ld_q, k0, ld_k0, vt0, ld_vt0, n0, b, nq, heads, dh, *, k0_bs, vt0_bs, seg1=None, n1_batches=0, kv_fp8=False):
         c = heads * dh
         out = self.arena.alloc((b, nq, c), F16)
         kw = {}
@@ -438,7 +448,7 @@ class NetEngine:
             k1, ld_k1, vt1, ld_vt1, n1, k1_bs, vt1_bs = seg1
             kw = dict(k1=k1, vt1=vt1, n1=n1, ld_k1=ld_k1, ld_vt1=ld_vt1, k1_bs=k1_bs, vt1_bs=vt1_bs, n1_batches=n1_batches)
         ops.attention(q, k0, vt0, out, batch=b, heads=heads, nq=nq, d=dh, n0=n0, ld_q=ld_q, ld_k0=ld_k0, ld_vt0=ld_vt0,
-                      ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, q_prescaled=True, **kw)
+                      ld_out=c, q_bs=nq * ld_q, k0_bs=k0_bs, vt0_bs=vt0_bs, out_bs=nq * c, q_prescaled=True, kv_fp8=kv_fp8, **kw)
         _chk(out, f"attention b={b} nq={nq} n0={n0} d={dh} seg1={None if seg1 is None else seg1[4]}")
         return out
 
@@ -449,7 +459,6 @@ class NetEngine:
         a = self.arena
         xn = self.gn(x, st["gn"], eps=1e-6, silu=False)
         t = self.conv(xn, st["pin_w"], c, k=1, bias=st["pin_b"], lo=True)
-        ldv = (n + 7) & ~7
         for blk in st["blocks"]:
             if mode == "write":
                 dst = None if self._bank_out is None else self._bank_out[len(banks)].t
@@ -461,28 +470,37 @@ class NetEngine:
                     return None  # last bank entry written: the appearance net has no other output (cldm.py:497)
             else:
                 n1 = None if "qkv_ln" in blk else self.ln(t, blk["ln1"])
-            # fused q|k projection (token-major) + V^T
-            qk = a.alloc((b, n, 2 * c), F16)
-            vt = a.alloc((b, c, ldv), F16, zero=(ldv != n))
+            # fused q|k projection (token-major) + V^T; fp8 path: q fp16 [b,n,c], K as e4m3 [b,n,c], V^T as e4m3 [b,c,ldv]
+            fp8 = ATTN_FP8
+            ldv = kv_ld(n)
+            if fp8:
+                qk = a.alloc((b, n, c), F16)
+                k8 = a.alloc((b, n, c), U8)
+                vt = a.alloc((b, c, ldv), U8, zero=(ldv != n))
+                okw = dict(out=qk, ld_out=c, out_t=vt, n_tr_begin=2 * c, ld_t=ldv, k8=(k8, c, 2 * c, c), vt_fp8=True)
+            else:
+                qk = a.alloc((b, n, 2 * c), F16)
+                vt = a.alloc((b, c, ldv), F16, zero=(ldv != n))
+                okw = dict(out=qk, ld_out=2 * c, out_t=vt, n_tr_begin=2 * c, ld_t=ldv)
             if n1 is None:   # norm1 folded into the projection
                 wl, s1, s0 = blk["qkv_ln"]
-                ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
-                          n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), ln=(s1, s0, 1e-5), col_scale=(self.qscale(dh), c))
+                ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(), ln=(s1, s0, 1e-5),
+                          col_scale=(self.qscale(dh), c), **okw)
             else:
-                ops.igemm(n1.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c,
-                          out_t=vt, n_tr_begin=2 * c, ld_t=ldv, ws=self._ws(), col_scale=(self.qscale(dh), c))
+                ops.igemm(n1.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(),
+                          col_scale=(self.qscale(dh), c), **okw)
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
                 if self._bank_events is not None:
                     torch.cuda.current_stream().wait_event(self._bank_events[bank_idx])
                 bb, nb = bank.b, bank.hw
-                ldvb = (nb + 7) & ~7
+                ldvb = kv_ld(nb)
                 if isinstance(bank, BankKV):
                     kr, vtr = bank.k, bank.vt
                 else:
-                    kr = a.alloc((bb, nb, c), F16)
-                    vtr = a.alloc((bb, c, ldvb), F16, zero=(ldvb != nb))
+                    kr = a.alloc((bb, nb, c), U8 if fp8 else F16)
+                    vtr = a.alloc((bb, c, ldvb), U8 if fp8 else F16, zero=(ldvb != nb))
                     self._project_bank(blk, bank, kr, vtr)
                 if bb == 1:
                     seg1 = (kr, c, vtr, ldvb, nb, 0, 0)
@@ -490,8 +508,12 @@ class NetEngine:
                     assert bb >= nread, "bank batch must be 1 (shared) or cover the read samples"
                     seg1 = (kr, c, vtr, ldvb, nb, nb * c, c * ldvb)
                 n1b = nread
-            att = self.attention(qk, 2 * c, qk[:, :, c:], 2 * c, vt, ldv, n, b, n, heads, dh, k0_bs=n * 2 * c,
-                                 vt0_bs=c * ldv, seg1=seg1, n1_batches=n1b)
+            if fp8:
+                att = self.attention(qk, c, k8, c, vt, ldv, n, b, n, heads, dh, k0_bs=n * c, vt0_bs=c * ldv, seg1=seg1,
+                                     n1_batches=n1b, kv_fp8=True)
+            else:
+                att = self.attention(qk, 2 * c, qk[:, :, c:], 2 * c, vt, ldv, n, b, n, heads, dh, k0_bs=n * 2 * c,
+                                     vt0_bs=c * ldv, seg1=seg1, n1_batches=n1b)
             t = self.conv(Act(att, b, 1, n, c), blk["o1_w"], c, k=1, bias=blk["o1_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
             # cross attention to the text context (attention.py:318)
             if "q2_ln" in blk:
@@ -519,8 +541,12 @@ class NetEngine:
 
     def _project_bank(self, blk, bank, k_out, vt_out):
         bb, nb, c = bank.b, bank.hw, bank.c
+        if ATTN_FP8:   # both halves as e4m3 bytes (K row-major, V^T transposed)
+            ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
+                      out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws(), k8=(k_out, 0, c, c), vt_fp8=True)
+            return
         ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
-                  out_t=vt_out, n_tr_begin=c, ld_t=(nb + 7) & ~7, ws=self._ws())
+                  out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws())
 
     def project_bank(self, e, bank, k_out, vt_out):
         """K / V^T of bank entry ``e`` (read order = _all_st order, one transformer block each in SD-1.5) for a whole

@@ -24,8 +24,9 @@ RECORD = None
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None):
-    """See md_igemm.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
+          col_scale=None, k8=None, vt_fp8=False):
+    """See md_igemm.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
+    end, ld): those columns as e4m3 bytes; ``vt_fp8``: the transposed columns as e4m3 bytes.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
     p.a0, p.a1, p.c0, p.c1 = _p(a0), _p(a1), c0, c1
@@ -37,6 +38,9 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.res_lo, p.out_lo = _p(res_lo), _p(out_lo)
     if col_scale is not None:
         p.col_scale, p.col_scale_end = float(col_scale[0]), int(col_scale[1])
+    if k8 is not None:
+        p.k8, p.k8_begin, p.k8_end, p.ld_k8 = _p(k8[0]), int(k8[1]), int(k8[2]), int(k8[3])
+    p.vt_fp8 = int(vt_fp8)
     p.act = act
     p.out, p.ld_out, p.out_f32 = _p(out), (ld_out if ld_out is not None else n), int(out_f32)
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
@@ -47,12 +51,12 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
-        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo)))
+        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8)))
     return out
 
 
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False):
     lib = _lib.load()
     p = AttentionParams()
     p.q, p.q_batch_stride, p.ld_q = _p(q), q_bs, ld_q
@@ -65,6 +69,7 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
     p.batch, p.heads, p.nq, p.d = batch, heads, nq, d
     p.scale = float(d) ** -0.5 if scale is None else scale
     p.q_prescaled = int(q_prescaled)
+    p.kv_fp8 = int(kv_fp8)
     _lib.check(lib.md_attention(C.byref(p), stream_ptr()), "md_attention")
     if RECORD is not None:
         nb1 = min(n1_batches, batch) if k1 is not None else 0

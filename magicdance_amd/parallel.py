@@ -151,7 +151,7 @@ class FrameShardedSampler:
             st.counter.zero_()
             ops.select_row_f32(st.ts_table, st.counter, 0, st.t_cur, 2 * b, st.S)
             ops.gather_rows(st.bank_table, st.bank_seg, st.bank_seg.shape[0], st.bank_seg_max, st.counter, 0, st.bank_cur,
-                            st.S, st.per, st.block_elems // 8)
+                            st.S, st.per, st.block_elems // st.table_unit)
             unet.arena.reset()
             pres = [Act(p.t.clone(), p.b, p.h, p.w, p.c) for p in pose_e.pose(st.x, st.hint_feat, st.t_cur[:b], st.kv_pose)]
             bref = st.ref.shape[0]

@@ -20,7 +20,7 @@ def _mem(t, size, stride):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None):
+          col_scale=None, k8=None, vt_fp8=False):
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -62,8 +62,21 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     ntr0 = n if n_tr_begin is None else n_tr_begin
     if ntr0 < n:
         ntr = n - ntr0
-        _mem(out_t, (batch, ntr, tokens), (ntr * ld_t, ld_t, 1)).copy_(y[..., ntr0:].transpose(1, 2))
+        yt = y[..., ntr0:].transpose(1, 2)
+        if vt_fp8:
+            _mem(out_t, (batch, ntr, tokens), (ntr * ld_t, ld_t, 1)).copy_(_to_e4m3(yt))
+        else:
+            _mem(out_t, (batch, ntr, tokens), (ntr * ld_t, ld_t, 1)).copy_(yt)
         y = y[..., :ntr0]
+    if k8 is not None:
+        kt, k0_, k1_, ldk = k8
+        _mem(kt, (batch, tokens, k1_ - k0_), (tokens * ldk, ldk, 1)).copy_(_to_e4m3(y[..., k0_:k1_]))
+        assert k0_ == 0 or k1_ == ntr0, "emulator: the fp8 columns are a prefix or a suffix of the row-major part"
+        if k0_ == 0:
+            if k1_ == ntr0:
+                return out
+            raise NotImplementedError
+        y, ntr0 = y[..., :k0_], k0_
     if res is not None:
         y = y + _mem(res, (batch, tokens, ntr0), (tokens * ld_res, ld_res, 1)).float()
         if res_lo is not None:
@@ -75,11 +88,35 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     return out
 
 
+def _to_e4m3(t):
+    """fp32 -> OCP e4m3 bytes (saturating, as the hardware conversion)"""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _from_e4m3(t):
+    return t.view(torch.float8_e4m3fn).float()
+
+
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False):
     scale = d ** -0.5 if scale is None else scale
     if q_prescaled:   # q carries scale * log2(e): q.k is the log2-domain logit
         scale = math.log(2.0)
+    if kv_fp8:   # e4m3 K / V^T bytes; q and P are rounded to e4m3 too, row sums use the unrounded P (as the kernel does)
+        dec = lambda t, size, stride: _from_e4m3(_mem(t, size, stride))  # noqa: E731
+        qq = _mem(q, (batch, heads, nq, d), (q_bs, d, ld_q, 1)).float() * (scale / math.log(2.0))
+        qq = _from_e4m3(_to_e4m3(qq))
+        o = _mem(out, (batch, heads, nq, d), (out_bs, d, ld_out, 1))
+        for b in range(batch):
+            kb = dec(k0, (batch, heads, n0, d), (k0_bs, d, ld_k0, 1))[b]
+            vb = dec(vt0, (batch, heads, n0, d), (vt0_bs, d * ld_vt0, 1, ld_vt0))[b]
+            if k1 is not None and b < n1_batches:
+                kb = torch.cat([kb, dec(k1, (batch, heads, n1, d), (k1_bs, d, ld_k1, 1))[b]], 1)
+                vb = torch.cat([vb, dec(vt1, (batch, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1))[b]], 1)
+            s2 = torch.einsum("hid,hjd->hij", qq[b], kb)
+            p = torch.exp2(s2 - s2.max(-1, keepdim=True).values)
+            o[b].copy_(torch.einsum("hij,hjd->hid", _from_e4m3(_to_e4m3(p)), vb) / p.sum(-1, keepdim=True))
+        return out
     qq = _mem(q, (batch, heads, nq, d), (q_bs, d, ld_q, 1)).float()
     kk = _mem(k0, (batch, heads, n0, d), (k0_bs, d, ld_k0, 1)).float()
     vv = _mem(vt0, (batch, heads, n0, d), (vt0_bs, d * ld_vt0, 1, ld_vt0)).float()

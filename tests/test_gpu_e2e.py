@@ -256,3 +256,31 @@ def test_text_context_from_the_clip_wrapper(dev):
     c2, uc2 = mk(want.clone())
     z2, _ = model.sample_log(cond=c2, unconditional_conditioning=uc2, **kw)
     assert bool(torch.isfinite(z1).all()) and _rel(z1.cpu().numpy(), z2.cpu().numpy(), "clip-wrapper context vs direct tensor") <= 1e-5
+
+
+def test_fp8_attention_path_parity_bound(dev):
+    """BASELINE configs[4]'s fp8 MFMA attention path (engine.ATTN_FP8: K / V^T / bank table in OCP e4m3, fp8 contractions) against
+    the reference golden AND against the fp16 path: stated bound 4e-2 relative for eps, 6e-2 for the 10-step latent (measured
+    ~1e-2: profiles/round2_parity_fp8.txt); the fp16 path stays the parity path."""
+    from magicdance_amd import engine
+    g = H.load_golden("small_b1")
+    inp = H.case_inputs(g)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long, device=dev)
+    c, uc = _to_dev(inp["c"], dev), _to_dev(inp["uc"], dev)
+    x_T, ref = inp["x_T"].to(dev), inp["ref"].to(dev)
+    m16 = _model(g, dev)
+    e16 = m16.apply_model(x_T, t, c, ref).cpu().numpy()
+    engine.ATTN_FP8 = True
+    try:
+        m8 = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device=dev, image_size=int(g["side"]))
+        e_c = m8.apply_model(x_T, t, c, ref).cpu().numpy()
+        e_u = m8.apply_model(x_T, t, c, None, uc=True).cpu().numpy()
+        z, _ = m8.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
+                             unconditional_conditioning=uc, inpaint=None, x_T=x_T)
+        assert m8._fused is not None and m8._fused.bank_table.dtype == torch.uint8
+    finally:
+        engine.ATTN_FP8 = False
+    assert _rel(e_c, g["eps_c"], "fp8 attention: eps_c vs golden") <= 4e-2
+    assert _rel(e_u, g["eps_u"], "fp8 attention: eps_u vs golden") <= 4e-2
+    assert _rel(e_c, e16, "fp8 attention: eps_c vs the fp16 path") <= 4e-2
+    assert _rel(z.cpu().numpy(), g["z"], "fp8 attention: z(10 steps) vs golden") <= 6e-2

@@ -59,7 +59,8 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+                                 34, 35, 36, 37])
 def test_igemm_conv(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cins, h, w, cout, k, stride, ups = case
@@ -129,6 +130,47 @@ def test_igemm_two_term_residual(dev, splitk):
     assert _err(_nchw32(out, b, h, w), ref) <= 1.2e-3 * scale          # hi alone: one fp16 rounding
     assert _err(got, ref) <= 2e-5 * scale                              # hi + lo: fp32 accumulation-order noise only
     assert float(out_lo.float().abs().max()) <= 2.0 ** -11 * scale * 1.01
+
+
+@pytest.mark.parametrize("cfg", [34, 35, 36, 37])
+def test_igemm_m32_tiles_epilogues(dev, cfg):
+    """32x32x16-fragment tiles: GEGLU pairing inside a 32-row fragment, split-K slabs, two-term residual, per-column scale,
+    transposed V^T store, M and N tails."""
+    from magicdance_amd import ops, engine
+    b, n, c = 2, 200, 128   # M = 400: not a multiple of the tile
+    x = _rand((b, n, c), 1, dev).to(F16)
+    xr = x.float()
+    w1, b1 = _rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1)
+    wp, bp = engine.pack_geglu(w1, b1, dev)
+    og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
+    ops.igemm(x, wp, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og, ld_out=4 * c,
+              force_cfg=cfg)
+    hr = xr @ w1.half().float().t() + b1
+    a, g = hr.chunk(2, dim=-1)
+    assert _err(og, a * F.gelu(g)) <= 6e-3
+    # fused q|k + V^T store with the q columns scaled, N = 3c = 384 (tail for the 160-wide tiles)
+    wq = _rand((3 * c, c), 2, dev, c ** -0.5)
+    qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
+    vt = torch.zeros((b, c, 208), dtype=F16, device=dev)
+    ops.igemm(x, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
+              n_tr_begin=2 * c, ld_t=208, col_scale=(0.25, c), force_cfg=cfg)
+    ref = xr @ wq.half().float().t()
+    assert _err(qk[..., :c], ref[..., :c] * 0.25) <= 4e-3 and _err(qk[..., c:], ref[..., c:2 * c]) <= 4e-3
+    assert _err(vt[:, :, :n], ref[..., 2 * c:].transpose(1, 2)) <= 4e-3
+    # 3x3 conv, split-K, two-term residual
+    xc = _rand((2, 128, 8, 8), 5, dev)
+    wt = _rand((128, 128, 3, 3), 6, dev, (128 * 9) ** -0.5)
+    res32 = _rand((2, 128, 8, 8), 7, dev, 3.0)
+    res_hi = _nhwc16(res32)
+    res_lo = (res32.permute(0, 2, 3, 1).reshape(2, 64, 128) - res_hi.float()).to(F16).contiguous()
+    refc = F.conv2d(xc.half().float(), wt.half().float(), None, padding=1) + _nchw32(res_hi.float() + res_lo.float(), 2, 8, 8)
+    out = torch.empty((2, 64, 128), dtype=F16, device=dev)
+    out_lo = torch.empty((2, 64, 128), dtype=F16, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    for sk in (1, 3):
+        ops.igemm(_nhwc16(xc), engine.pack_conv(wt, dev), 128, batch=2, hin=8, win=8, hout=8, wout=8, c0=128, ksize=3, res=res_hi,
+                  ld_res=128, res_lo=res_lo, out=out, out_lo=out_lo, ws=ws, force_cfg=cfg, force_splitk=sk)
+        assert _err(_nchw32(out.float() + out_lo.float(), 2, 8, 8), refc) <= 3e-5 * float(refc.abs().max()), sk
 
 
 def test_igemm_linear_f32_transposed_geglu(dev):
@@ -242,6 +284,77 @@ def test_attention_prescaled_q_and_col_scale(dev):
     s_ = torch.einsum("bhid,bhjd->bhij", sp(ref_qk[..., :c].half()), sp(qk[..., c:])) * d ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", s_.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, n, c)
     assert _err(out, ref) <= 4e-3
+
+
+def _e4m3(t):
+    return t.float().clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("case", [("d40_bank", 2, 4, 192, 192, 200, 1, 40), ("d80", 1, 2, 130, 330, 0, 0, 80), ("d160_bank", 2, 1, 96, 160, 100, 2, 160),
+                                  ("d64_tiny", 1, 2, 16, 16, 16, 1, 64)], ids=lambda c: c[0])
+def test_attention_fp8(dev, case):
+    """md_attention kv_fp8 (BASELINE configs[4] path): K / V^T as OCP e4m3 bytes, q and P converted in registers, fp8 MFMA with
+    fp32 accumulation.  Checked against fp32 attention over the SAME e4m3 operands (K, V, q): what remains is the e4m3 rounding
+    of P (3 mantissa bits, uniform over the keys -> averages out) -- 2e-2 abs on O(1) outputs; and against the unquantised fp32
+    attention with the path's stated bound, 8e-2."""
+    from magicdance_amd import ops
+    name, b, heads, nq, n0, n1, n1b, d = case
+    c = heads * d
+    q = _rand((b, nq, c), 1, dev).to(F16)
+    k0f, v0f = _rand((b, n0, c), 2, dev), _rand((b, n0, c), 3, dev)
+    ld0 = (n0 + 15) // 16 * 16
+    k0 = _e4m3(k0f)
+    vt0 = torch.zeros((b, c, ld0), dtype=torch.float8_e4m3fn, device=dev)
+    vt0[:, :, :n0] = _e4m3(v0f.transpose(1, 2))
+    kw = {}
+    if n1:
+        k1f, v1f = _rand((b, n1, c), 4, dev), _rand((b, n1, c), 5, dev)
+        ld1 = (n1 + 15) // 16 * 16
+        k1 = _e4m3(k1f)
+        vt1 = torch.zeros((b, c, ld1), dtype=torch.float8_e4m3fn, device=dev)
+        vt1[:, :, :n1] = _e4m3(v1f.transpose(1, 2))
+        kw = dict(k1=k1.view(torch.uint8), vt1=vt1.view(torch.uint8), n1=n1, ld_k1=c, ld_vt1=ld1, k1_bs=n1 * c, vt1_bs=c * ld1, n1_batches=n1b)
+    out = torch.empty((b, nq, c), dtype=F16, device=dev)
+    ops.attention(q, k0.view(torch.uint8), vt0.view(torch.uint8), out, batch=b, heads=heads, nq=nq, d=d, n0=n0, ld_q=c, ld_k0=c,
+                  ld_vt0=ld0, ld_out=c, q_bs=nq * c, k0_bs=n0 * c, vt0_bs=c * ld0, out_bs=nq * c, kv_fp8=True, **kw)
+    sp = lambda t: t.float().reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3)  # noqa: E731
+    qs = d ** -0.5 * 1.4426950408889634
+    ref_q, ref = torch.empty((b, nq, c), dtype=F32, device=dev), torch.empty((b, nq, c), dtype=F32, device=dev)
+    for i in range(b):
+        kq, vq, kk, vv = k0[i:i + 1].float(), vt0[i:i + 1, :, :n0].float().transpose(1, 2), k0f[i:i + 1], v0f[i:i + 1]
+        if n1 and i < n1b:
+            kq, vq = torch.cat([kq, k1[i:i + 1].float()], 1), torch.cat([vq, vt1[i:i + 1, :, :n1].float().transpose(1, 2)], 1)
+            kk, vv = torch.cat([kk, k1f[i:i + 1]], 1), torch.cat([vv, v1f[i:i + 1]], 1)
+        q8 = _e4m3(q[i:i + 1].float() * qs).float()
+        s_q = torch.einsum("bhid,bhjd->bhij", sp(q8), sp(kq)) * math.log(2.0)
+        ref_q[i] = torch.einsum("bhij,bhjd->bhid", s_q.softmax(-1), sp(vq)).permute(0, 2, 1, 3).reshape(nq, c)
+        s_f = torch.einsum("bhid,bhjd->bhij", sp(q[i:i + 1]), sp(kk)) * d ** -0.5
+        ref[i] = torch.einsum("bhij,bhjd->bhid", s_f.softmax(-1), sp(vv)).permute(0, 2, 1, 3).reshape(nq, c)
+    assert _err(out, ref_q) <= 2e-2, name
+    assert _err(out, ref) <= 8e-2, name
+
+
+def test_igemm_fp8_outputs(dev):
+    """md_igemm k8 / vt_fp8: the K columns and the transposed V columns of a fused q|k|v projection as OCP e4m3 bytes."""
+    from magicdance_amd import ops
+    b, n, c = 2, 72, 64
+    x = _rand((b, n, c), 1, dev).to(F16)
+    wq = _rand((3 * c, c), 2, dev, c ** -0.5)
+    qo = torch.empty((b, n, c), dtype=F16, device=dev)
+    k8 = torch.zeros((b, n, c), dtype=torch.uint8, device=dev)
+    ldv = 80
+    vt8 = torch.zeros((b, c, ldv), dtype=torch.uint8, device=dev)
+    ops.igemm(x, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qo, ld_out=c, out_t=vt8,
+              n_tr_begin=2 * c, ld_t=ldv, k8=(k8, c, 2 * c, c), vt_fp8=True, col_scale=(0.5, c))
+    ref = x.float() @ wq.half().float().t()
+    assert _err(qo, ref[..., :c] * 0.5) <= 4e-3
+    kd, vd = k8.view(torch.float8_e4m3fn).float(), vt8.view(torch.float8_e4m3fn).float()
+    rk, rv = ref[..., c:2 * c], ref[..., 2 * c:].transpose(1, 2)
+    # e4m3: 3 mantissa bits -> relative 2^-4, plus the subnormal step 2^-9 near zero
+    assert bool(((kd - rk).abs() <= rk.abs() * 2.0 ** -4 + 2.0 ** -9).all())
+    assert bool(((vd[:, :, :n] - rv).abs() <= rv.abs() * 2.0 ** -4 + 2.0 ** -9).all())
+    assert float(vd[:, :, n:].abs().max()) == 0.0
+    assert torch.equal(k8, _e4m3(rk).view(torch.uint8)) or float(((kd - _e4m3(rk).float()).abs() > 0).float().mean()) < 0.02   # ties / fp32 order
 
 
 def test_attention_spike_rescale(dev):

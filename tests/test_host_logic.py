@@ -241,3 +241,26 @@ def test_overlap_sampling_route_matches_reference_golden(monkeypatch):
                             img_callback=lambda p0, i: traj.append(p0.clone()))
     assert _rel(z.numpy(), g["z"]) <= 2e-2
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"]) <= 2e-2
+
+
+def test_fp8_attention_path_host_logic(monkeypatch):
+    """engine.ATTN_FP8: e4m3 K / V^T buffers, 16-byte-row leading dimensions, byte-unit table segments, fp8 bank table through the
+    fused (table) route -- emulated kernels; bound as stated for the path (4e-2 / 6e-2)."""
+    hip_emulator.install(monkeypatch)
+    from magicdance_amd import engine
+    monkeypatch.setattr(engine, "ATTN_FP8", True)
+    _no_graph(monkeypatch)
+    g = H.load_golden("small_b1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu", image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long)
+    assert _rel(model.apply_model(inp["x_T"], t, inp["c"], inp["ref"]).numpy(), g["eps_c"]) <= 4e-2
+    z, _ = model.sample_log(cond=inp["c"], batch_size=1, ddim=True, ddim_steps=4, eta=0.0, unconditional_guidance_scale=7,
+                            unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"])
+    st = model._fused
+    assert st is not None and st.bank_table.dtype == torch.uint8 and st.table_unit == 16
+    smp = __import__("magicdance_amd.ddim", fromlist=["x"]).DDIMSampler_ReferenceOnly(model)
+    smp.make_schedule(4, ddim_eta=0.0)
+    z2, _ = smp.ddim_sampling(inp["c"], tuple(inp["x_T"].shape), x_T=inp["x_T"], unconditional_guidance_scale=7,
+                              unconditional_conditioning=inp["uc"], force_generic=True)
+    assert _rel(z.numpy(), z2.numpy()) <= 3e-2     # table route vs generic route, both fp8

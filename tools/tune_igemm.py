@@ -72,6 +72,9 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
         cfgs += [28] + ([29, 30, 31] if (N % 80 == 0 and act != 2) else [])   # two k-tiles per stage
         if M <= 4096:
             cfgs += [32] + ([33] if (N % 80 == 0 and act != 2) else [])       # four
+    ln_shape = ks == 1 and c1 == 0 and K in (320, 640, 1280) and N in (K, 3 * K, 8 * K)   # possibly a folded-LayerNorm GEMM
+    if buf_ok and not ln_shape and M >= 2048:
+        cfgs += [34, 36] + ([35, 37] if N % 160 == 0 or N >= 640 else [])   # 32x32x16-fragment tiles
     if buf_ok and os.environ.get("TUNE_DEEP"):
         cfgs += list(range(16, 24))  # counted-vmcnt 3..6-stage pipelines (exploration only, see igemm.hip)
     nk = (K + 63) // 64

@@ -95,7 +95,7 @@ def cpu_baseline(model, inp, size, z_hip=None, img_hip=None, steps=3):
                 h_u = model.apply_model(inp["x_T"], t.to(dev), cd, None, uc=True).cpu()
                 rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
                 parity = {"eps_cond_rel_max_abs": rel(h_c, e_c), "eps_uncond_rel_max_abs": rel(h_u, e_u),
-                          "note": f"HIP fp16 path vs fp32 CPU oracle, t={int(ts[0])}, same synthetic weights/inputs"}
+                          "note": f"HIP path vs fp32 CPU oracle, t={int(ts[0])}, same synthetic weights/inputs"}
             e = e_u + 7.0 * (e_c - e_u)
             a_t, a_p = float(alphas[index]), float(alphas_prev[index])
             x = (a_p ** 0.5) * (x - (1.0 - a_t) ** 0.5 * e) / (a_t ** 0.5) + (1.0 - a_p) ** 0.5 * e

@@ -107,6 +107,16 @@ typedef struct {
   void* k8;
   int32_t k8_begin, k8_end, ld_k8;
   int32_t vt_fp8;
+  /* Second parameter set (ABI v3): samples b >= batch2 use w2 / bias2 / ln2_s1 / ln2_s0 instead of w / bias / ln_s1 / ln_s0
+   * (same shapes, bias_batch_stride must be 0).  One launch then serves two networks of identical geometry whose samples sit
+   * behind each other in the batch: the SD-1.5 UNet's encoder + middle block on the cond / uncond samples and the pose
+   * ControlNet's trainable copy of them (cldm/cldm.py:736-757 next to :86-91) on its own.  (Two GEMMs stacked along M: the second
+   * set's tiles start at row batch2 * hout * wout.)  batch2 <= 0 or w2 == NULL: one parameter set. */
+  const void* w2;
+  const float* bias2;
+  const float* ln2_s1;
+  const float* ln2_s0;
+  int32_t batch2;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
@@ -157,6 +167,8 @@ typedef struct {
   int32_t silu;
   void* out;                                        /* fp16 [B][hw][c0+c1] */
   void* ws; int64_t ws_bytes;
+  const float* gamma2; const float* beta2;          /* ABI v3: samples b >= batch2 use this affine pair (see md_igemm batch2) */
+  int32_t batch2;                                   /* <= 0 or gamma2 == NULL: one parameter set */
 } md_groupnorm_params;
 int md_groupnorm(const md_groupnorm_params* p, void* stream);
 int64_t md_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);

@@ -27,6 +27,7 @@ class IgemmParams(C.Structure):
         ("ln_eps", C.c_float), ("asym_pad", C.c_int32), ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
         ("col_scale", C.c_float), ("col_scale_end", C.c_int32), ("k8", C.c_void_p), ("k8_begin", C.c_int32),
         ("k8_end", C.c_int32), ("ld_k8", C.c_int32), ("vt_fp8", C.c_int32),
+        ("w2", C.c_void_p), ("bias2", C.c_void_p), ("ln2_s1", C.c_void_p), ("ln2_s0", C.c_void_p), ("batch2", C.c_int32),
     ]
 
 
@@ -49,6 +50,7 @@ class GroupNormParams(C.Structure):
         ("x0", C.c_void_p), ("x1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32), ("batch", C.c_int32),
         ("hw", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("silu", C.c_int32), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("gamma2", C.c_void_p), ("beta2", C.c_void_p), ("batch2", C.c_int32),
     ]
 
 

@@ -58,6 +58,12 @@ struct IgemmArgs {
   const float* ln_s1;
   const float* ln_s0;
   float ln_eps, ln_inv_k;
+  // second parameter set: rows m >= m_split use w2 / bias2 / ln2_* and form their own m-tiles, tile_m >= tiles_m1 (INT_MAX: one set)
+  const half_t* w2;
+  const float* bias2;
+  const float* ln2_s1;
+  const float* ln2_s0;
+  int m_split, tiles_m1;
   int early_w;  // MD_IGEMM_EARLY_W (default 1): first-tile W loads ahead of the row setup
   int dbg;  // MD_IGEMM_DEBUG bit mask (component timing only, results are garbage): 1 no MFMA, 2 no LDS reads + MFMA, 4 no k-loop loads
 };
@@ -69,8 +75,9 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
 
 // Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed).
 __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int n, f4 v) {
-  if (g.bias) {
-    const f4 bv = *reinterpret_cast<const f4*>(g.bias + (long long)b * g.bias_bs + n);
+  const float* bias = m >= g.m_split ? g.bias2 : g.bias;
+  if (bias) {
+    const f4 bv = *reinterpret_cast<const f4*>(bias + (long long)b * g.bias_bs + n);
     v += bv;
   }
   if (n < g.col_scale_end) v *= g.col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
@@ -193,10 +200,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const int first_m = grp * g.group_m;
   const int gsz = min(g.tiles_m - first_m, g.group_m);
   const int tile_n = in_grp / gsz, tile_m = first_m + (in_grp - tile_n * gsz);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // two parameter sets = two GEMMs stacked along M: the second one's tiles start AT m_split (not at a multiple of BM), the
+  // first one's rows end there
+  const bool set2 = tile_m >= g.tiles_m1;
+  const int m0 = set2 ? g.m_split + (tile_m - g.tiles_m1) * BM : tile_m * BM;
+  const int Mlim = set2 ? g.M : min(g.M, g.m_split);
+  const int n0 = tile_n * BN;
   const int kz = blockIdx.z;
   const int kt_begin = kz * g.tiles_per_split;
   const int kt_end = min(g.nk, kt_begin + g.tiles_per_split);
+  // parameter set of this tile
+  const half_t* const gw = set2 ? g.w2 : g.w;
+  [[maybe_unused]] const float* const gbias = set2 ? g.bias2 : g.bias;
+  [[maybe_unused]] const float* const gln_s1 = set2 ? g.ln2_s1 : g.ln_s1;
+  [[maybe_unused]] const float* const gln_s0 = set2 ? g.ln2_s0 : g.ln_s0;
 
   // ---- loader role: LDS slot (row, lc) for rows lrow + 32 j; fixed global k-chunk gc -------------------------
   const int lc = tid & 7, lrow = tid >> 3;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       }
       const unsigned ksoff0 = (unsigned)(tap0 * g.cin + cc0) * 2u;
       const __amdgpu_buffer_rsrc_t rs_w0 =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), 0, g.N * g.K * 2, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
       char* Ws0 = smem + BM * 128;
 #pragma unroll
       for (int j = 0; j < (BN + 31) / 32; ++j) {
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   int a_y[AJ], a_x[AJ], a_pix[AJ], a_mask[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int m = min(m0 + lrow + 32 * j, g.M - 1);  // rows past M are computed on a clamped row and never stored
+    const int m = min(m0 + lrow + 32 * j, Mlim - 1);  // rows past the end are computed on a clamped row and never stored
     const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
     const int rem = m - b * g.tokens;
     const int oy = fast_div(rem, g.div_w_mul, g.div_w_sh);
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   }
   const half_t* w_ptr[WJ];
 #pragma unroll
-  for (int j = 0; j < WJ; ++j) w_ptr[j] = g.w + (long long)min(n0 + lrow + 32 * j, g.N - 1) * g.K;
+  for (int j = 0; j < WJ; ++j) w_ptr[j] = gw + (long long)min(n0 + lrow + 32 * j, g.N - 1) * g.K;
   const half_t* zero = reinterpret_cast<const half_t*>(md_zero_page);
 
   // (tap, channel) of this thread's k-chunk, advanced by 64 channels per k-tile
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<half_t*>(g.a1 ? g.a1 : g.a0) - (long long)shift_pix * (g.a1 ? g.c1 : g.c0), 0,
       (g.batch * g.hin * g.win + shift_pix) * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), 0, g.N * g.K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;  // beyond any tensor: the load returns zeros
 
   // BUF loader: the launcher guarantees cin % 64 == 0 and c0 % 64 == 0, so a 64-channel k-tile lies in ONE tap of ONE
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int n = min(n0 + wn * WTN + i * 32 + 8 * q + 4 * lh, g.N - 4);
-            const f4 s1 = *reinterpret_cast<const f4*>(g.ln_s1 + n), s0 = *reinterpret_cast<const f4*>(g.ln_s0 + n);
+            const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc32[i][j][4 * q + e] = rstd * (acc32[i][j][4 * q + e] - mu * s1[e]) + s0[e];
           }
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
     for (int j = 0; j < MF32; ++j) {
       const int m = m0 + wm * WTM + j * 32 + l31;
-      if (m >= g.M) continue;
+      if (m >= Mlim) continue;
       const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
 #pragma unroll
       for (int i = 0; i < NF32; ++i) {
@@ -623,9 +640,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
             if (np + 16 >= g.N) continue;
             f4 av = {acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
             f4 gv = {acc32[i][j][4 * q + 8], acc32[i][j][4 * q + 9], acc32[i][j][4 * q + 10], acc32[i][j][4 * q + 11]};
-            if (g.bias) {
-              av += *reinterpret_cast<const f4*>(g.bias + np);
-              gv += *reinterpret_cast<const f4*>(g.bias + np + 16);
+            if (gbias) {
+              av += *reinterpret_cast<const f4*>(gbias + np);
+              gv += *reinterpret_cast<const f4*>(gbias + np + 16);
             }
             h4 o;
 #pragma unroll
@@ -664,7 +681,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         const int n = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4);
-        const f4 s1 = *reinterpret_cast<const f4*>(g.ln_s1 + n), s0 = *reinterpret_cast<const f4*>(g.ln_s0 + n);
+        const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
         acc[i][j] = rstd * (acc[i][j] - mu * s1) + s0;
       }
     }
@@ -673,7 +690,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
       const int m = m0 + wm * WTM + j * 16 + lr;
-      if (m >= g.M) continue;
+      if (m >= Mlim) continue;
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         const int n = n0 + wn * WTN + i * 16 + lg * 4;
@@ -688,15 +705,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
       for (int j = 0; j < MF; ++j) {
         const int m = m0 + wm * WTM + j * 16 + lr;
-        if (m >= g.M) continue;
+        if (m >= Mlim) continue;
 #pragma unroll
         for (int i = 0; i < NF; i += 2) {
           const int np = n0 + wn * WTN + i * 16 + lg * 4;  // packed row of the "a" half; gate rows are +16
           if (np + 16 >= g.N) continue;
           f4 av = acc[i][j], gv = acc[i + 1][j];
-          if (g.bias) {
-            av += *reinterpret_cast<const f4*>(g.bias + np);
-            gv += *reinterpret_cast<const f4*>(g.bias + np + 16);
+          if (gbias) {
+            av += *reinterpret_cast<const f4*>(gbias + np);
+            gv += *reinterpret_cast<const f4*>(gbias + np + 16);
           }
           h4 o;
 #pragma unroll
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int m = m0 + wm * WTM + j * 16 + lr;
-    if (m >= g.M) continue;
+    if (m >= Mlim) continue;
     const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
@@ -843,6 +860,12 @@ int validate(const md_igemm_params* p) {
   if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
   if (p->bias_batch_stride & 3) return MD_ERR_BAD_ARG;
+  if (p->w2 && p->batch2 > 0) {
+    if (p->batch2 >= p->batch || p->bias_batch_stride) return MD_ERR_UNSUPPORTED;
+    if ((p->bias != nullptr) != (p->bias2 != nullptr) || (p->ln_s1 != nullptr) != (p->ln2_s1 != nullptr) ||
+        (p->ln_s0 != nullptr) != (p->ln2_s0 != nullptr))
+      return MD_ERR_BAD_ARG;
+  }
   if (p->act == MD_ACT_GEGLU) {
     if ((p->n & 31) || p->res || p->out_f32 || p->n_tr_begin != p->n || p->bias_batch_stride) return MD_ERR_UNSUPPORTED;
   } else if (p->act != MD_ACT_NONE && p->act != MD_ACT_SILU) {
@@ -866,9 +889,14 @@ int g_use_tuned = [] {
 // Pick tile config + split-K: tuned table first, otherwise a crude time model (overridable: force_cfg / force_splitk).
 void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_bytes, int* cfg_out, int* split_out) {
   const int nk = (K + 63) / 64;
-  if (g_use_tuned && p->force_cfg < 0 && p->force_splitk <= 0) {
+  // two parameter sets: a batch of 3F samples (2F UNet + F ControlNet) is not in the table -- the entry of the 2F-sample layer
+  // (same N, K, tile economics; 1.5x the workgroups) is the second choice before the model below
+  const long long M_alt = (p->w2 && p->batch2 > 0) ? (long long)p->batch2 * p->hout * p->wout : M;
+  for (int pass = 0; pass < 2 && g_use_tuned && p->force_cfg < 0 && p->force_splitk <= 0; ++pass) {
+    const long long Mq = pass == 0 ? M : M_alt;
+    if (pass == 1 && M_alt == M) break;
     for (const TunedEntry* t = kTuned; t->m; ++t) {
-      if (t->m == M && t->n == N && t->k == K && t->ksize == p->ksize && t->stride == p->stride && t->ups == p->ups) {
+      if (t->m == Mq && t->n == N && t->k == K && t->ksize == p->ksize && t->stride == p->stride && t->ups == p->ups) {
         const bool ok_split = t->split == 1 || (p->act != MD_ACT_GEGLU && (long long)t->split * M * N * 4 <= ws_bytes);
         const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
         const bool ok_act = cfg_geglu_ok(t->cfg) || p->act != MD_ACT_GEGLU;
@@ -978,6 +1006,12 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.ln_s1 = p->ln_s1;
   g.ln_s0 = p->ln_s0;
   g.ln_eps = p->ln_eps;
+  const bool dual = p->w2 && p->batch2 > 0;
+  g.w2 = dual ? (const half_t*)p->w2 : g.w;
+  g.bias2 = dual ? p->bias2 : g.bias;
+  g.ln2_s1 = dual ? p->ln2_s1 : g.ln_s1;
+  g.ln2_s0 = dual ? p->ln2_s0 : g.ln_s0;
+  g.m_split = dual ? p->batch2 * g.tokens : 0x7fffffff;
   g.ln_inv_k = 1.0f / (float)g.K;
   static const int early_w = [] {
     const char* e = getenv("MD_IGEMM_EARLY_W");
@@ -999,6 +1033,11 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
+  g.tiles_m1 = 0x7fffffff;
+  if (dual) {
+    g.tiles_m1 = (g.m_split + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
+    g.tiles_m = g.tiles_m1 + (g.M - g.m_split + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;
+  }
   g.tiles_n = (g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn;
   {  // ~64 workgroups are resident per XCD: make them a (group_m x tiles_n) block of the tile grid
     static const int gm_env = [] {

@@ -26,6 +26,9 @@ struct GnArgs {
   float eps;
   const float* gamma;
   const float* beta;
+  const float* gamma2;   // samples b >= batch2 (second network of a merged batch)
+  const float* beta2;
+  int batch2;
   int silu;
   half_t* out;
   float* ws;  // [batch][nchunks][groups][2]
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs g) {
   for (int u = 0; u < 16; ++u) {
     const int c = threadIdx.x + 256 * u;
     if (c < g.c) {
-      gm[u] = g.gamma[c];
-      bt[u] = g.beta[c];
+      gm[u] = (b >= g.batch2 ? g.gamma2 : g.gamma)[c];
+      bt[u] = (b >= g.batch2 ? g.beta2 : g.beta)[c];
     }
   }
   __syncthreads();
@@ -246,10 +249,12 @@ __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int
   __syncthreads();
   if (!active) return;
   float sc[8], sh[8];
+  const float* gamma = b >= g.batch2 ? g.gamma2 : g.gamma;
+  const float* beta = b >= g.batch2 ? g.beta2 : g.beta;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    sc[e] = stat[GN_GPER_MAX + lg[e]] * g.gamma[c + e];
-    sh[e] = g.beta[c + e] - stat[lg[e]] * sc[e];
+    sc[e] = stat[GN_GPER_MAX + lg[e]] * gamma[c + e];
+    sh[e] = beta[c + e] - stat[lg[e]] * sc[e];
   }
   half_t* dst = g.out + c;
 #pragma unroll
@@ -371,6 +376,10 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   g.eps = p->eps;
   g.gamma = p->gamma;
   g.beta = p->beta;
+  const bool dual = p->gamma2 && p->beta2 && p->batch2 > 0;
+  g.gamma2 = dual ? p->gamma2 : p->gamma;
+  g.beta2 = dual ? p->beta2 : p->beta;
+  g.batch2 = dual ? p->batch2 : 0x7fffffff;
   g.silu = p->silu;
   g.out = (half_t*)p->out;
   g.ws = (float*)p->ws;

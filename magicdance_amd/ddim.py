@@ -250,6 +250,9 @@ class FusedStepRunner:
         # (2.48 vs 2.55 frames/s at configs[1]): a zero-conv may overwrite a skip only after the UNet's next block has read it, so the
         # pose stream is throttled to the UNet's pace and its tail lands on the critical path.  Off by default (MD_FUSE_POSE=1 enables).
         self.fuse_pose = os.environ.get("MD_FUSE_POSE", "0") == "1"
+        # The pose ControlNet as extra samples of the UNet's encoder launches (NetEngine.unet_pose; default).  MD_MERGE_POSE=0: its
+        # own ~110 launches on a concurrent stream (the round-1 / early round-2 form, kept for comparison).
+        self.merge_pose = os.environ.get("MD_MERGE_POSE", "1") == "1"
         self.table_chunks = int(os.environ.get("MD_TABLE_CHUNKS", "2"))  # sharded: all-gathers per table (2nd overlaps the loop)
         self.tkey = None
         self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
@@ -295,6 +298,7 @@ class FusedStepRunner:
         self.kv_app = app.context_kv(self._ctx_app)
         self.kv_pose = pose_e.context_kv(self._ctx_app if self._ctx_app.shape[0] in (1, b) else self._ctx_src)
         self.kv_unet = unet.context_kv(self._ctx_unet)
+        self.kv_merged = unet.merged_context_kv(self.kv_unet, self.kv_pose, b) if self.merge_pose and self.overlap == 3 else None
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
         bref = ref.shape[0]
@@ -543,7 +547,11 @@ class FusedStepRunner:
                     app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app, bank_out=banks)
                     app._bank_events = None
                 unet._bank_events = self.bank_events
-            if self.fuse_pose:
+            if self.merge_pose:
+                # the pose ControlNet rides in the UNet encoder's launches (second parameter set): no stream of its own
+                eps = unet.unet_pose(pose_e, self.x, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
+                                     self.emb_cur_pose, banks=banks, nread=b, only_mid_control=model.only_mid_control)
+            elif self.fuse_pose:
                 # pose ControlNet on its own stream from the START of the step (it only needs x, the hint features and the time
                 # embedding), its zero-convs adding into the UNet's skips / middle output in place as soon as the UNet's down path
                 # no longer reads them; host order: UNet down path, pose net, UNet up path.

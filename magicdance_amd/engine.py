@@ -171,6 +171,42 @@ class Act:
         return Act(self.t[:nb], nb, self.h, self.w, self.c, None if self.lo is None else self.lo[:nb])
 
 
+    def tail(self, nb):
+        """samples nb.. (the second network's samples of a merged batch)"""
+        return Act(self.t[nb:], self.b - nb, self.h, self.w, self.c, None if self.lo is None else self.lo[nb:])
+
+
+class Dual:
+    """The same parameter of two networks of identical geometry that run as ONE batch: ``a`` serves the samples below the
+    engine's ``_batch2``, ``b`` the samples from there on (md_igemm / md_groupnorm second parameter set)."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def __getitem__(self, idx):
+        return Dual(self.a[idx], self.b[idx])
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+
+def zip_params(u, p):
+    """packed layers of two structurally identical networks -> one structure whose tensors are Dual pairs"""
+    if isinstance(u, dict):
+        assert u.keys() == p.keys(), (sorted(u), sorted(p))
+        return {k: zip_params(u[k], p[k]) for k in u}
+    if isinstance(u, (list, tuple)):
+        assert len(u) == len(p)
+        return type(u)(zip_params(x, y) for x, y in zip(u, p))
+    if isinstance(u, torch.Tensor):
+        assert u.shape == p.shape and u.dtype == p.dtype
+        return Dual(u, p)
+    assert u == p, (u, p)
+    return u
+
+
 class BankKV:
     """One bank entry already projected by the UNet's own to_k / to_v (attention.py:303-311 computes
     to_k(cat[x, bank]), linear in the tokens): K [b, n, c] and V^T [b, c, ldv] fp16, the form md_attention's second
@@ -204,6 +240,8 @@ class NetEngine:
         self._bank_events = None   # per-bank-entry events when appearance and UNet run on concurrent streams
         self._pose_ready = None    # (stream to wait on) before the first pose residual is consumed
         self.ws_slot = 0
+        self._batch2 = None        # first sample of the second parameter set while a merged (two-network) pass is running
+        self._merged = None
         self._write_stop_at = sum(len(st["blocks"]) for st in self._all_st()) if self.kind == "appearance" else -1
 
     # ------------------------------------------------------------------ weight packing
@@ -318,6 +356,7 @@ class NetEngine:
         nout = n // 2 if act == MD_ACT_GEGLU else n
         if out is None:
             out = self.arena.alloc((x.b, hout * wout, nout), F32 if out_f32 else F16)
+        w, bias, ln, set2 = self._sets(w, bias, ln)
         if isinstance(lo, torch.Tensor):   # explicit second-term buffer (in-place residual epilogue)
             out_lo = lo
         else:
@@ -325,9 +364,22 @@ class NetEngine:
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
-                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale)
+                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale,
+                  set2=set2)
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
         return Act(out, x.b, hout, wout, nout, out_lo)
+
+    def _sets(self, w, bias, ln):
+        """(w, bias, ln, set2) of a GEMM whose parameters may be Dual pairs (merged two-network pass)"""
+        if not isinstance(w, Dual):
+            return w, bias, ln, None
+        assert self._batch2 is not None
+        assert bias is None or isinstance(bias, Dual)
+        ln2 = None
+        if ln is not None:
+            ln2 = (ln[0].b, ln[1].b)
+            ln = (ln[0].a, ln[1].a, ln[2])
+        return w.a, (None if bias is None else bias.a), ln, (self._batch2, w.b, None if bias is None else bias.b, ln2)
 
     def _gn_ws(self):
         """GroupNorm partial sums: a small scratch of its own (the igemm workspace starts with arrival counters)."""
@@ -340,15 +392,23 @@ class NetEngine:
     def gn(self, x, gb, *, x1=None, eps=1e-5, silu=True):
         c = x.c + (0 if x1 is None else x1.c)
         out = self.arena.alloc((x.b, x.hw, c), F16)
+        set2 = None
+        if isinstance(gb[0], Dual):
+            set2, gb = (self._batch2, gb[0].b, gb[1].b), (gb[0].a, gb[1].a)
         ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
-                      c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu)
+                      c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu, set2=set2)
         _chk(out, f"groupnorm c={c} hw={x.hw} b={x.b}")
         return Act(out, x.b, x.h, x.w, c)
 
     def ln(self, x, gb, out=None):
         if out is None:
             out = self.arena.alloc((x.b, x.hw, x.c), F16)
-        ops.layernorm(x.t, gb[0], gb[1], out, x.b * x.hw, x.c)
+        if isinstance(gb[0], Dual):   # merged pass, LayerNorm not folded (channel counts that are no multiple of 64): two row ranges
+            b2 = self._batch2
+            ops.layernorm(x.t, gb[0].a, gb[1].a, out, b2 * x.hw, x.c)
+            ops.layernorm(x.t[b2:], gb[0].b, gb[1].b, out[b2:], (x.b - b2) * x.hw, x.c)
+        else:
+            ops.layernorm(x.t, gb[0], gb[1], out, x.b * x.hw, x.c)
         _chk(out, f"layernorm c={x.c} rows={x.b * x.hw}")
         return Act(out, x.b, x.h, x.w, x.c)
 
@@ -484,11 +544,13 @@ class NetEngine:
                 okw = dict(out=qk, ld_out=2 * c, out_t=vt, n_tr_begin=2 * c, ld_t=ldv)
             if n1 is None:   # norm1 folded into the projection
                 wl, s1, s0 = blk["qkv_ln"]
-                ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(), ln=(s1, s0, 1e-5),
-                          col_scale=(self.qscale(dh), c), **okw)
+                wl, _, lnp, set2 = self._sets(wl, None, (s1, s0, 1e-5))
+                ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(), ln=lnp,
+                          col_scale=(self.qscale(dh), c), set2=set2, **okw)
             else:
-                ops.igemm(n1.t, blk["qkv_w"], 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(),
-                          col_scale=(self.qscale(dh), c), **okw)
+                wq, _, _, set2 = self._sets(blk["qkv_w"], None, None)
+                ops.igemm(n1.t, wq, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(),
+                          col_scale=(self.qscale(dh), c), set2=set2, **okw)
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
@@ -541,6 +603,8 @@ class NetEngine:
 
     def _project_bank(self, blk, bank, k_out, vt_out):
         bb, nb, c = bank.b, bank.hw, bank.c
+        if isinstance(blk["qkv_w"], Dual):   # merged pass: the bank is read by the UNet's samples, through the UNet's to_k / to_v
+            blk = {"qkv_w": blk["qkv_w"].a}
         if ATTN_FP8:   # both halves as e4m3 bytes (K row-major, V^T transposed)
             ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
                       out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws(), k8=(k_out, 0, c, c), vt_fp8=True)
@@ -695,6 +759,81 @@ class NetEngine:
         hn = self.gn(h, self.head_gn, silu=True)
         if eps_out is None:
             eps_out = self.arena.alloc((b, h.hw, self.cfg.out_channels), F32)
+        self.conv(hn, self.head_w, self.cfg.out_channels, k=3, bias=self.head_b, out_f32=True, out=eps_out)
+        return eps_out
+
+    def merged_params(self, pose_e):
+        """input / middle blocks of this UNet zipped with the pose ControlNet's trainable copy of them (cldm.py:559-733 builds
+        the same input_blocks / middle_block as openaimodel.py:527-660): every tensor becomes a Dual pair"""
+        if self._merged is None or self._merged[0] is not pose_e:
+            assert self.kind == "unet" and pose_e.kind == "pose"
+            self._merged = (pose_e, [zip_params(u, p) for u, p in zip(self.input_blocks, pose_e.input_blocks)],
+                            zip_params(self.middle_block, pose_e.middle_block))
+        return self._merged[1], self._merged[2]
+
+    def merged_context_kv(self, ctx_kv, pose_kv, b):
+        """cross-attention K / V^T of the merged encoder: per transformer block, the UNet's rows for its 2b samples followed by
+        the ControlNet's rows for its b samples (small: 77 tokens; built once per context, cached on the source buffers)"""
+        key = (ctx_kv[0][0].data_ptr(), pose_kv[0][0].data_ptr(), b)
+        cache = getattr(self, "_merged_kv", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        out = []
+        for (ku, vu, bu, tk, ldv), (kp, vp, bp, tkp, ldvp) in zip(ctx_kv, pose_kv):   # zip stops after the encoder + middle blocks
+            assert (tk, ldv) == (tkp, ldvp) and bu in (1, 2 * b) and bp in (1, b)
+            k = torch.cat([ku.expand(2 * b, -1, -1), kp.expand(b, -1, -1)], 0).contiguous()
+            vt = torch.cat([vu.expand(2 * b, -1, -1), vp.expand(b, -1, -1)], 0).contiguous()
+            out.append((k, vt, 3 * b, tk, ldv))
+        self._merged_kv = (key, out, (ctx_kv, pose_kv))
+        return out
+
+    def unet_pose(self, pose_e, x, hint_feat, ctx_kv, ctx_kv_merged, emb, emb_pose, banks=None, nread=0, only_mid_control=False,
+                  eps_out=None):
+        """One DDIM step's UNet (cond + uncond samples, cldm.py:59-112) and pose ControlNet (cldm.py:736-757) as ONE pass: the
+        ControlNet is a copy of the UNet's input + middle blocks with its own weights and the same input x_t, so its b samples
+        ride behind the UNet's 2b in every launch of the encoder (second parameter set of md_igemm / md_groupnorm) instead of
+        running ~110 small launches of their own on a concurrent stream.  What remains of the ControlNet: the guided-hint add
+        after the stem (:744-747) and the 13 zero-convs (:733-734), whose epilogues add straight into the skip / middle tensors
+        of the cond samples (:93-95, 102-104) -- issued after the encoder, which must read those tensors unmodified.
+        x: fp32 latent [b, 4, H, W]; emb / emb_pose: ONE row each (all samples share the timestep)."""
+        assert self.kind == "unet" and emb.shape[0] == 1 and emb_pose.shape[0] == 1 and nread in (0, x.shape[0])
+        b = int(x.shape[0])
+        b2 = 2 * b
+        use_bank_in = nread > 0 and banks is not None and len(banks) > 0
+        use_bank = use_bank_in and not only_mid_control                            # cldm.py:98-106
+        inb, mid = self.merged_params(pose_e)
+        hs, ctx_idx, bank_idx = [], [0], [0]
+        mode = "read" if use_bank_in else None
+        self._batch2 = b2
+        try:
+            demb = Dual(emb, emb_pose)
+            h = self.stem_input([x, x, x])
+            for i, blk in enumerate(inb):
+                h = self.run_block(blk, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
+                if i == 0:   # h += guided_hint on the ControlNet's samples
+                    hp = h.tail(b2)
+                    ops.add_f16(hp.t, hint_feat.t, hp.t, hp.b * hp.hw * hp.c, hint_feat.b * hint_feat.hw * hint_feat.c)
+                hs.append(h)
+            h = self.run_block(mid, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
+        finally:
+            self._batch2 = None
+
+        def zero_conv(src, z, tgt):
+            hp, tg = src.tail(b2), tgt.head(nread)
+            self.conv(hp, z["w"], hp.c, k=1, bias=z["b"], res=tg, out=tg.t, lo=tg.lo if tg.lo is not None else False)
+
+        if nread > 0:
+            zero_conv(h, pose_e.mid_out, h)                                        # cldm.py:93-95
+            if not only_mid_control and use_bank:
+                for i, hi in enumerate(hs):
+                    zero_conv(hi, pose_e.zero_convs[i], hi)                        # cldm.py:102-104
+        h = h.head(b2)
+        for blk in self.output_blocks:
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, "read" if use_bank else None, banks, bank_idx, nread,
+                               x1=hs.pop().head(b2))
+        hn = self.gn(h, self.head_gn, silu=True)
+        if eps_out is None:
+            eps_out = self.arena.alloc((b2, h.hw, self.cfg.out_channels), F32)
         self.conv(hn, self.head_w, self.cfg.out_channels, k=3, bias=self.head_b, out_f32=True, out=eps_out)
         return eps_out
 

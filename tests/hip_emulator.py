@@ -17,10 +17,31 @@ def _mem(t, size, stride):
     return t.as_strided(size, stride, t.storage_offset())
 
 
+def _off(t, elems):
+    """pointer + elems (in elements of t's dtype)"""
+    return t.as_strided((1,), (1,), t.storage_offset() + elems)
+
+
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False):
+          col_scale=None, k8=None, vt_fp8=False, set2=None):
+    if set2 is not None:   # two parameter sets: samples >= batch2 use (w2, bias2, ln2) -- two plain calls on the two sample ranges
+        b2, w2, bias2, ln2 = set2
+        assert 0 < b2 < batch and bias_batch_stride == 0
+        tok = hout * wout
+        ntr0_ = n if n_tr_begin is None else n_tr_begin
+        ldo = (n if ld_out is None else ld_out)
+        kw = dict(hin=hin, win=win, hout=hout, wout=wout, c0=c0, ksize=ksize, stride=stride, ups=ups, c1=c1, ld_res=ld_res, act=act,
+                  ld_out=ld_out, out_f32=out_f32, n_tr_begin=n_tr_begin, ld_t=ld_t, ws=ws, asym_pad=asym_pad, col_scale=col_scale,
+                  vt_fp8=vt_fp8)
+        igemm(a0, w, n, batch=b2, a1=a1, bias=bias, res=res, out=out, out_t=out_t, ln=ln, res_lo=res_lo, out_lo=out_lo, k8=k8, **kw)
+        o = lambda t, e: None if t is None else _off(t, e)  # noqa: E731
+        igemm(_off(a0, b2 * hin * win * c0), w2, n, batch=batch - b2, a1=o(a1, b2 * hin * win * c1), bias=bias2,
+              res=o(res, b2 * tok * ld_res), out=_off(out, b2 * tok * ldo), out_t=o(out_t, b2 * (n - ntr0_) * ld_t),
+              ln=None if ln is None else (ln2[0], ln2[1], ln[2]), res_lo=o(res_lo, b2 * tok * ld_res),
+              out_lo=o(out_lo, b2 * tok * ldo), k8=None if k8 is None else (_off(k8[0], b2 * tok * k8[3]),) + tuple(k8[1:]), **kw)
+        return out
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
     if a1 is not None:
@@ -136,7 +157,15 @@ def groupnorm_ws_bytes(batch, hw, groups=32):
     return 1024
 
 
-def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False):
+def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None):
+    if set2 is not None:
+        b2, gamma2, beta2 = set2
+        assert 0 < b2 < batch
+        kw = dict(hw=hw, c0=c0, c1=c1, groups=groups, eps=eps, silu=silu)
+        groupnorm(x0, gamma, beta, out, ws, batch=b2, x1=x1, **kw)
+        groupnorm(_off(x0, b2 * hw * c0), gamma2, beta2, _off(out, b2 * hw * (c0 + c1)), ws, batch=batch - b2,
+                  x1=None if x1 is None else _off(x1, b2 * hw * c1), **kw)
+        return out
     xs = [_mem(x0, (batch, hw, c0), (hw * c0, c0, 1)).float()]
     if x1 is not None:
         xs.append(_mem(x1, (batch, hw, c1), (hw * c1, c1, 1)).float())

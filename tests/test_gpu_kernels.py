@@ -590,3 +590,93 @@ def test_igemm_folded_layernorm_geglu_and_transposed(dev):
               n_tr_begin=2 * c, ld_t=tokens, ln=(s1, s0, 1e-5))
     assert _err(qk, y3[..., :2 * c]) <= 6e-3 * max(1.0, float(y3.abs().max()))
     assert _err(vt, y3[..., 2 * c:].transpose(1, 2)) <= 6e-3 * max(1.0, float(y3.abs().max()))
+
+
+@pytest.mark.parametrize("case", [("c3", 3, 2, 320, 8, 8, 128, 3, 1), ("c3_ragged", 3, 2, 64, 6, 6, 96, 3, 1), ("c1", 6, 4, 320, 16, 16, 320, 1, 1),
+                                  ("down", 3, 2, 128, 16, 16, 128, 3, 2), ("stem", 3, 2, 8, 16, 16, 64, 3, 1), ("big", 3, 2, 320, 64, 64, 320, 3, 1)])
+@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (12, 1), (25, 1), (27, 1), (29, 2), (32, 1), (15, 3), (34, 1), (3, 1), (7, 1)])
+def test_igemm_second_parameter_set(dev, case, cfg, splitk):
+    """md_igemm w2 / bias2 / batch2 (ABI v3): samples >= batch2 use the second weight / bias set.  One launch must reproduce, BIT
+    FOR BIT, two launches on the two sample ranges with the same tile config (the tiles of the second set start at its first row;
+    6x6 images: that row is no multiple of any tile height), with bias, SiLU, a two-term residual and split-K."""
+    from magicdance_amd import ops, engine
+    name, b, b2, cin, h, w, cout, k, stride = case
+    if cin % 64 and cfg >= 12:
+        pytest.skip("buffer loader needs 64-channel k-tiles")
+    if cfg in (3, 7) and splitk == 1 and name == "big":
+        pytest.skip("slow register-staged tiles on the big case")
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    x = _nhwc16(_rand((b, cin, h, w), 1, dev))
+    wa = engine.pack_conv(_rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5), dev)
+    wb = engine.pack_conv(_rand((cout, cin, k, k), 3, dev, (cin * k * k) ** -0.5), dev)
+    ba, bb = _rand((cout,), 4, dev, 0.5), _rand((cout,), 5, dev, 0.5)
+    res = _rand((b, ho * wo, cout), 6, dev).to(F16)
+    res_lo = (_rand((b, ho * wo, cout), 7, dev) * 1e-4).to(F16)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    kw = dict(hin=h, win=w, hout=ho, wout=wo, c0=cin, ksize=k, stride=stride, ld_res=cout, act=ops.MD_ACT_SILU, ws=ws,
+              force_cfg=cfg, force_splitk=splitk)
+    one, one_lo = torch.zeros((b, ho * wo, cout), dtype=F16, device=dev), torch.zeros((b, ho * wo, cout), dtype=F16, device=dev)
+    ops.igemm(x, wa, cout, batch=b, bias=ba, res=res, res_lo=res_lo, out=one, out_lo=one_lo, set2=(b2, wb, bb, None), **kw)
+    two, two_lo = torch.zeros_like(one), torch.zeros_like(one)
+    ops.igemm(x, wa, cout, batch=b2, bias=ba, res=res, res_lo=res_lo, out=two, out_lo=two_lo, **kw)
+    ops.igemm(x[b2:], wb, cout, batch=b - b2, bias=bb, res=res[b2:], res_lo=res_lo[b2:], out=two[b2:], out_lo=two_lo[b2:], **kw)
+    torch.cuda.synchronize()
+    if cfg < 0:   # auto: the merged and the separate launches may pick different tiles / splits -> accumulation-order noise only
+        assert _err(one, two) <= 4e-3 * max(1.0, float(two.float().abs().max())), (name, cfg)
+    else:
+        assert torch.equal(one, two) and torch.equal(one_lo, two_lo), (name, cfg, splitk)
+    assert float((one[:b2].float() - one[b2:b2 + 1].float()).abs().max()) > 0.05   # the two sets really differ
+
+
+def test_igemm_second_parameter_set_layernorm_geglu(dev):
+    """second parameter set with the folded LayerNorm (ln2_s1 / ln2_s0) on the fused q|k|v projection (V^T transposed store,
+    q columns scaled) and on the GEGLU projection: bit-identical to two launches."""
+    from magicdance_amd import ops, engine
+    b, b2, tokens, c = 3, 2, 64, 320
+    x16 = (_rand((b, tokens, c), 1, dev) + 0.3).to(F16)
+    sets = []
+    for s in (0, 10):
+        gamma, beta = 1.0 + _rand((c,), 4 + s, dev, 0.2), _rand((c,), 5 + s, dev, 0.2)
+        sets.append((engine.fold_layernorm(_rand((3 * c, c), 6 + s, dev, c ** -0.5), None, gamma, beta, dev),
+                     engine.fold_layernorm(_rand((8 * c, c), 7 + s, dev, c ** -0.5), _rand((8 * c,), 8 + s, dev, 0.1), gamma, beta, dev)))
+    (qa, ga), (qb, gb) = sets
+    kw = dict(hin=1, win=tokens, hout=1, wout=tokens, c0=c)
+
+    def qkv(x, bb, wset, out, vt, set2=None):
+        ops.igemm(x, wset[0], 3 * c, batch=bb, out=out, ld_out=2 * c, out_t=vt, n_tr_begin=2 * c, ld_t=tokens, ln=(wset[1], wset[2], 1e-5),
+                  col_scale=(0.3, c), set2=set2, **kw)
+
+    def geglu(x, bb, wset, out, set2=None):
+        ops.igemm(x, wset[0], 8 * c, batch=bb, out=out, ld_out=4 * c, act=ops.MD_ACT_GEGLU, ln=(wset[1], wset[2], 1e-5), set2=set2, **kw)
+    qk1, vt1 = torch.zeros((b, tokens, 2 * c), dtype=F16, device=dev), torch.zeros((b, c, tokens), dtype=F16, device=dev)
+    qk2, vt2 = torch.zeros_like(qk1), torch.zeros_like(vt1)
+    qkv(x16, b, qa, qk1, vt1, set2=(b2, qb[0], None, (qb[1], qb[2])))
+    qkv(x16, b2, qa, qk2, vt2)
+    qkv(x16[b2:], b - b2, qb, qk2[b2:], vt2[b2:])
+    f1, f2 = torch.zeros((b, tokens, 4 * c), dtype=F16, device=dev), torch.zeros((b, tokens, 4 * c), dtype=F16, device=dev)
+    geglu(x16, b, ga, f1, set2=(b2, gb[0], None, (gb[1], gb[2])))
+    geglu(x16, b2, ga, f2)
+    geglu(x16[b2:], b - b2, gb, f2[b2:])
+    torch.cuda.synchronize()
+    assert torch.equal(qk1, qk2) and torch.equal(vt1, vt2) and torch.equal(f1, f2)
+    assert float((qk1[0].float() - qk1[b2].float()).abs().max()) > 0.05
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 320, 16, 16), (3, 2, 320, 64, 64), (6, 4, 1280, 8, 8), (3, 2, 64, 8, 8), (3, 1, 640, 32, 32)])
+def test_groupnorm_second_parameter_set(dev, shape):
+    """md_groupnorm gamma2 / beta2 / batch2: samples >= batch2 get the second affine pair (all three kernels: gn_small and
+    gn_stats + gn_apply); bit-identical to two launches."""
+    from magicdance_amd import ops
+    b, b2, c, h, w = shape
+    x16 = _nhwc16(_rand((b, c, h, w), 1, dev) * 2 + 0.5)
+    ga, ba = 1 + 0.1 * _rand((c,), 2, dev), 0.1 * _rand((c,), 3, dev)
+    gb, bb = 1 + 0.1 * _rand((c,), 4, dev), 0.1 * _rand((c,), 5, dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    one, two = torch.zeros((b, h * w, c), dtype=F16, device=dev), torch.zeros((b, h * w, c), dtype=F16, device=dev)
+    ops.groupnorm(x16, ga, ba, one, ws, batch=b, hw=h * w, c0=c, silu=True, set2=(b2, gb, bb))
+    ops.groupnorm(x16, ga, ba, two, ws, batch=b2, hw=h * w, c0=c, silu=True)
+    ops.groupnorm(x16[b2:], gb, bb, two[b2:], ws, batch=b - b2, hw=h * w, c0=c, silu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    ref = F.silu(F.group_norm(_nchw32(x16[b2:], b - b2, h, w), 32, gb, bb, eps=1e-5))
+    assert _err(_nchw32(one[b2:], b - b2, h, w), ref) <= 4e-3

@@ -264,3 +264,48 @@ def test_fp8_attention_path_host_logic(monkeypatch):
     z2, _ = smp.ddim_sampling(inp["c"], tuple(inp["x_T"].shape), x_T=inp["x_T"], unconditional_guidance_scale=7,
                               unconditional_conditioning=inp["uc"], force_generic=True)
     assert _rel(z.numpy(), z2.numpy()) <= 3e-2     # table route vs generic route, both fp8
+
+
+def test_merged_pose_pass_matches_separate_pose_pass(monkeypatch):
+    """The pose ControlNet as extra samples of the UNet encoder's launches (md_igemm / md_groupnorm second parameter set,
+    NetEngine.unet_pose; default) against its own launches on a side stream (MD_MERGE_POSE=0): same arithmetic per sample, the
+    zero-conv adds fused into the GEMM epilogue instead of a separate fp16 add.  Checks that the merged route really is what the
+    fused step runs (second-set launches are issued, the ControlNet issues none of its own besides the zero-convs)."""
+    hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
+    from magicdance_amd import ddim, ops
+    g = H.load_golden("small_b2")
+    mc, nh = int(g["geo_model_channels"]), int(g["geo_num_heads"])
+    model = H.build_hip_model(mc, nh, seed=int(g["seed"]), device="cpu", image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    frames = int(g["frames"])
+    calls = {"set2": 0, "plain": 0, "gn2": 0}
+    orig_igemm, orig_gn = ops.igemm, ops.groupnorm
+
+    def igemm(*a, set2=None, **kw):
+        calls["set2" if set2 is not None else "plain"] += 1
+        return orig_igemm(*a, set2=set2, **kw)
+
+    def groupnorm(*a, set2=None, **kw):
+        calls["gn2"] += set2 is not None
+        return orig_gn(*a, set2=set2, **kw)
+    monkeypatch.setattr(ops, "igemm", igemm)
+    monkeypatch.setattr(ops, "groupnorm", groupnorm)
+    zs = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MD_MERGE_POSE", merge)
+        model._fused = None
+        for k in calls:
+            calls[k] = 0
+        z, _ = model.sample_log(cond=inp["c"], batch_size=frames, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                                unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"])
+        assert model._fused is not None and model._fused.merge_pose == (merge == "1")
+        zs[merge] = z.numpy()
+        if merge == "1":
+            assert calls["set2"] > 0 and calls["gn2"] > 0
+            per_step_set2 = calls["set2"] // int(g["steps"])
+        else:
+            assert calls["set2"] == 0 and calls["gn2"] == 0
+    assert per_step_set2 >= 20
+    assert _rel(zs["1"], g["z"]) <= 2e-2
+    assert _rel(zs["1"], zs["0"]) <= 5e-3

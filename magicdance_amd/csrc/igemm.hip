@@ -450,12 +450,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     for (int i = 0; i < LNF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
   }
 
-  auto compute_tile = [&](int stage) {
+  auto no_mid = [] {};
+  auto compute_tile = [&](int stage, auto&& mid) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Ws = As + BM * 128;
 #ifdef MD_IGEMM_DEBUG  // component timing build (tools/igemm_parts.py): -DMD_IGEMM_DEBUG, masks from the environment
-    if (g.dbg & 2) return;
+    if (g.dbg & 2) {
+      mid();
+      return;
+    }
     if (g.dbg & 1) {  // LDS operand reads only
+      mid();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int chunk = ks * 4 + lg;
@@ -476,20 +481,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     }
 #endif
     if constexpr (M32) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {   // four 16-deep k-steps per 64-deep tile; lane half lh holds k = 8 lh .. 8 lh + 7 of a step
-        h8 af[MF32], wf[NF32];
+      // four 16-deep k-steps per 64-deep tile; lane half lh holds k = 8 lh .. 8 lh + 7 of a step.  All fragments of the tile are
+      // requested before the first MFMA (steps 0-1, then the next tile's LDS-DMA issue, then steps 2-3), as in the 16-row form.
+      h8 af[4][MF32], wf[4][NF32];
+      auto load32 = [&](int ks) {
         const int chunk = ks * 2 + lh;
 #pragma unroll
         for (int i = 0; i < MF32; ++i) {
           const int row = wm * WTM + i * 32 + l31;
-          af[i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+          af[ks][i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int i = 0; i < NF32; ++i) {
           const int row = wn * WTN + i * 32 + l31;
-          wf[i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+          wf[ks][i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
         }
+      };
+      load32(0);
+      load32(1);
+      __builtin_amdgcn_sched_barrier(0);
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+      load32(2);
+      load32(3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
         if constexpr (LN) {
           typedef _Float16 h2v __attribute__((ext_vector_type(2)));
           const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
           for (int i = 0; i < MF32; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const h2v p = {af[i][2 * e], af[i][2 * e + 1]};
+              const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
               ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
               ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
             }
@@ -507,24 +524,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         for (int i = 0; i < NF32; ++i)
 #pragma unroll
           for (int j = 0; j < MF32; ++j)
-            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc32[i][j], 0, 0, 0);
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], af[ks][j], acc32[i][j], 0, 0, 0);
       }
       return;
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8 af[MF], wf[NF];
+    // Both 32-deep k-steps of the tile: ALL operand fragments are requested from LDS before the first MFMA (the compiler, left
+    // alone, keeps one ds_read_b128 in flight per pair of MFMAs -- ~70 idle MFMA cycles per pair at one or two waves per SIMD),
+    // and ``mid`` (the next tile's LDS-DMA issue: address VALU + buffer_load..lds) runs while the first fragments are in flight.
+    h8 af[2][MF], wf[2][NF];
+    auto load_frags = [&](int ks) {
       const int chunk = ks * 4 + lg;
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         const int row = wm * WTM + i * 16 + lr;
-        af[i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ (row & 7)) << 4));
+        af[ks][i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         const int row = wn * WTN + i * 16 + lr;
-        wf[i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ (row & 7)) << 4));
+        wf[ks][i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ (row & 7)) << 4));
       }
+    };
+    load_frags(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mid();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
       if constexpr (LN) {
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
@@ -532,7 +560,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         for (int i = 0; i < MF; ++i) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const h2v p = {af[i][2 * e], af[i][2 * e + 1]};
+            const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
             ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
             ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
           }
@@ -542,11 +570,71 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < MF; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
     }
   };
 
-  if constexpr (GLDS && STAGES > 2) {
+  if constexpr (M32) {
+    // ---- 32x32x16 fragments: software-pipelined k-loop ------------------------------------------------------------------
+    // Register-only loops of v_mfma_f32_16x16x32_f16 sustain 1.3-1.6 PFLOP/s on this chip, 32x32x16 chains 2.15-2.23
+    // (profiles/round2_mfma_issue_rate.txt): a wave cannot issue the short MFMA back to back.  With the long one the MFMA pipe is
+    // fed by ONE wave per SIMD -- if that wave never stops for LDS.  So the operand fragments are double-buffered in registers at
+    // k-step granularity: the ds_read_b128 of step s + 1 are issued before the MFMAs of step s.  The tile boundary sits before the
+    // LAST step of a tile: wait for the next tile's LDS-DMA (issued one whole tile earlier) and for this wave's last fragment
+    // reads of the current stage, barrier, re-arm the current stage with the tile after next, read the next tile's first
+    // fragments -- then the last step's MFMAs run while all of that is in flight.  Two LDS stages, always vmcnt(0).
+    static_assert(!LN, "the folded-LayerNorm GEMMs use the 16-row tiles");
+    h8 fa[2][MF32], fw[2][NF32];
+    auto rd = [&](int stage, int ks, int buf) {
+      const char* As = smem + stage * STAGE_BYTES;
+      const char* Ws = As + BM * 128;
+      const int chunk = ks * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < MF32; ++i) {
+        const int row = wm * WTM + i * 32 + l31;
+        fa[buf][i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < NF32; ++i) {
+        const int row = wn * WTN + i * 32 + l31;
+        fw[buf][i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < NF32; ++i)
+#pragma unroll
+        for (int j = 0; j < MF32; ++j)
+          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[buf][i], fa[buf][j], acc32[i][j], 0, 0, 0);
+    };
+    if (kt_begin < kt_end) {
+      fetch_tile(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt_begin + 1 < kt_end) fetch_tile(1);
+      rd(0, 0, 0);
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int stage = (kt - kt_begin) & 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int buf = ks & 1;
+        if (ks < 3) {
+          rd(stage, ks + 1, buf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (kt + 1 < kt_end) {
+          // every wave holds its last fragments of `stage` in registers and the next tile has landed -> the stage may be re-armed
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __syncthreads();
+          rd(stage ^ 1, 0, buf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt + 2 < kt_end) fetch_tile(stage);   // its address VALU / DMA issue interleaves with the MFMAs below
+        }
+        mma(buf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if constexpr (GLDS && STAGES > 2) {
     constexpr int LPT = AJ + WJ;  // LDS-DMA instructions per thread per k-tile
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) fetch_tile(s, kt_begin + s < kt_end);
@@ -555,8 +643,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");  // tile kt has landed (this wave's part)
       __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the stage refilled next
       const int refill = stage == 0 ? STAGES - 1 : stage - 1;
-      fetch_tile(refill, kt + STAGES - 1 < kt_end);
-      compute_tile(stage);
+      compute_tile(stage, [&] { fetch_tile(refill, kt + STAGES - 1 < kt_end); });
       stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the zero-page tail fetches before LDS is released
@@ -582,21 +669,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tiles kt.. have landed for every wave; every wave is done with stage^1
 #ifdef MD_IGEMM_DEBUG
-        if (more && !(g.dbg & 4))
+        const bool issue = more && !(g.dbg & 4);
 #else
-        if (more)
+        const bool issue = more;
 #endif
-        {
+        // the refill of stage^1 is issued from INSIDE the first tile's compute, behind its first fragment reads
+        auto refill = [&] {
+          if (issue) {
 #pragma unroll
-          for (int u = 0; u < KT; ++u) fetch_tile((stage ^ 1) * KT + u, kt + KT + u < kt_end);
-        }
+            for (int u = 0; u < KT; ++u) fetch_tile((stage ^ 1) * KT + u, kt + KT + u < kt_end);
+          }
+        };
+        compute_tile(stage * KT, refill);
+#pragma unroll
+        for (int u = 1; u < KT; ++u)
+          if (kt + u < kt_end) compute_tile(stage * KT + u, no_mid);
       } else {
         if (more) fetch_tile(stage ^ 1);
-      }
-#pragma unroll
-      for (int u = 0; u < KT; ++u)
-        if (KT == 1 || kt + u < kt_end) compute_tile(stage * KT + u);
-      if constexpr (!GLDS) {
+        compute_tile(stage, no_mid);
         if (more) store_tile(stage ^ 1);
         __syncthreads();
       }

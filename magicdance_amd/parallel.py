@@ -132,7 +132,7 @@ class FrameShardedSampler:
     def network_pass_times(self, pose, ctx, ref, x_T, ddim_steps=50, scale=7.0, reps=5):
         """Metric (ii) of SURVEY 8(d), "UNet ms/step": HIP-event time of ONE forward of each network at this batch size B =
         pose.shape[0] -- ``unet_read`` (ControlledUnetModelAttnPose read branch: bank attention + pose residuals), ``unet_uc``
-        (plain branch), ``pose`` (ControlNet incl. its 13 zero-convs), ``appearance`` (ControlNetReferenceOnly write pass, B = 1:
+        (plain branch), ``pose`` (ControlNet incl. its 13 zero-convs), ``unet_pose_merged`` (UNet 2B + ControlNet B as one pass, the default step), ``appearance`` (ControlNetReferenceOnly write pass, B = 1:
         the reference image is shared) and ``unet_cfg_2b`` (what a step actually launches: read + uc batched as 2B samples).
         Each pass is captured into a HIP graph and replayed ``reps`` times between two events on the launch stream."""
         from . import ops
@@ -152,6 +152,8 @@ class FrameShardedSampler:
             ops.select_row_f32(st.ts_table, st.counter, 0, st.t_cur, 2 * b, st.S)
             ops.gather_rows(st.bank_table, st.bank_seg, st.bank_seg.shape[0], st.bank_seg_max, st.counter, 0, st.bank_cur,
                             st.S, st.per, st.block_elems // st.table_unit)
+            ops.select_row_f32(st.emb_table_unet, st.counter, 0, st.emb_cur_unet, st.emb_cur_unet.shape[1], st.S)
+            ops.select_row_f32(st.emb_table_pose, st.counter, 0, st.emb_cur_pose, st.emb_cur_pose.shape[1], st.S)
             unet.arena.reset()
             pres = [Act(p.t.clone(), p.b, p.h, p.w, p.c) for p in pose_e.pose(st.x, st.hint_feat, st.t_cur[:b], st.kv_pose)]
             bref = st.ref.shape[0]
@@ -164,6 +166,10 @@ class FrameShardedSampler:
                 "pose": lambda: pose_e.pose(st.x, st.hint_feat, st.t_cur[:b], st.kv_pose),
                 "appearance": lambda: app.appearance(st.ref, st.t_cur[:bref], st.kv_app),
             }
+            if st.kv_merged is not None:   # what a step launches by default: UNet (2B samples) with the ControlNet's B samples riding
+                passes["unet_pose_merged"] = lambda: unet.unet_pose(   # in its encoder launches
+                    pose_e, st.x, st.hint_feat, st.kv_unet, st.kv_merged, st.emb_cur_unet, st.emb_cur_pose, banks=st.bank_cur_kv,
+                    nread=b, only_mid_control=model.only_mid_control)
             for name, fn in passes.items():
                 def run():
                     unet.arena.reset()

@@ -41,6 +41,13 @@ for fpg in batches:
         kv = dict(re.findall(r"(\w+)=(-?\d+)", tag))
         key = tuple(int(kv[k]) for k in ("M", "N", "K", "ks", "st", "up", "B", "h", "w", "c0", "c1", "act"))
         shapes[key] = shapes.get(key, 0) + 1
+if os.environ.get("TUNE_ONLY_NEW"):   # keep the committed table, time only the shapes it does not hold yet
+    have = set()
+    for line in open(os.path.join(ROOT, "magicdance_amd", "csrc", "igemm_tuned.inc")):
+        m = re.match(r"\s*\{(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),", line)
+        if m:
+            have.add(tuple(int(v) for v in m.groups()))
+    shapes = {k: v for k, v in shapes.items() if k[:6] not in have}
 print(f"{len(shapes)} unique igemm shapes", flush=True)
 del model
 torch.cuda.empty_cache()

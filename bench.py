@@ -213,6 +213,10 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), cand
+                # the counters were collected on a launch mix with more (smaller) igemm launches per batch (pose ControlNet on its
+                # own stream): same bytes per batch, re-expressed per launch of THIS run's mix
+                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"] and args.ddim_steps == 50 and fpg == 1:
+                    traffic = traffic * pmc["igemm_launches_per_batch"] / ig["launches"]
                 break
             except Exception:  # noqa: BLE001
                 pass

@@ -177,6 +177,28 @@ def test_variants_match_reference_golden(dev, name):
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], f"{name} pred_x0 trajectory vs golden") <= TOL_Z
 
 
+def test_merged_and_forked_pose_pass_agree(dev, monkeypatch):
+    """The default step rides the pose ControlNet's samples in the UNet encoder's launches (md_igemm / md_groupnorm second parameter
+    set, 3B samples per launch); MD_MERGE_POSE=0 runs the ControlNet's own launches on a forked stream.  Both must match the
+    reference golden, and each other to the fp16 rounding of the zero-conv add (fused into the GEMM epilogue in the merged form)."""
+    g = H.load_golden("small_b2")
+    model = _model(g, dev)
+    inp = H.case_inputs(g)
+    frames = int(g["frames"])
+    c, uc, x_T = _to_dev(inp["c"], dev), _to_dev(inp["uc"], dev), inp["x_T"].to(dev)
+    zs = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MD_MERGE_POSE", merge)
+        model._fused = None
+        z, _ = model.sample_log(cond=c, batch_size=frames, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                                unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=x_T)
+        assert model._fused is not None and model._fused.merge_pose == (merge == "1")
+        zs[merge] = z.cpu().numpy()
+        assert _rel(zs[merge], g["z"], f"small_b2 z, MD_MERGE_POSE={merge}, vs golden") <= TOL_Z
+    model._fused = None
+    assert _rel(zs["1"], zs["0"], "merged vs forked pose pass") <= 3e-3
+
+
 def test_repeated_sampling_is_bit_identical(dev):
     """The reference-KV table pass runs on its own stream ahead of the captured step graphs (own arena / workspaces): any
     missing dependency between the two would show up as run-to-run differences.  (tools/repeat_check.py: 30 full-size runs.)"""

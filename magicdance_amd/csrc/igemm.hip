@@ -73,49 +73,71 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
   return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
 }
 
-// Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed).
-__device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int n, f4 v) {
+// Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed).  Every global load the epilogue needs (bias,
+// residual, second residual term) is ISSUED before the first one is consumed: one memory round trip per call instead of three.
+// Epilogue-only parameters.  The k-loop kernel reads them from the kernarg segment AFTER the loop (scalar loads behind an opaque
+// pointer) into plain locals: as by-value kernel arguments they would be loaded at entry and held in SGPRs across the loop, which
+// pushed the kernel over the SGPR budget (spill to scratch at entry, scratch reload at the head of every wave's epilogue); as a
+// struct the compiler keeps them in scratch, hence the long-hand parameter list.
+#define MD_LATE_PARAMS                                                                                                          \
+  float e_col_scale, int e_col_scale_end, unsigned char *e_k8, int e_k8_begin, int e_k8_end, int e_ld_k8, int e_vt_fp8,        \
+      const half_t *e_res_lo, half_t *e_out_lo, half_t *e_out_t, int e_n_tr_begin, int e_ld_t
+#define MD_LATE_ARGS e_col_scale, e_col_scale_end, e_k8, e_k8_begin, e_k8_end, e_ld_k8, e_vt_fp8, e_res_lo, e_out_lo, e_out_t, e_n_tr_begin, e_ld_t
+#define MD_LATE_LOAD(src)                                                                                                       \
+  const float e_col_scale = (src).col_scale;                                                                                    \
+  const int e_col_scale_end = (src).col_scale_end;                                                                              \
+  unsigned char* const e_k8 = (src).k8;                                                                                         \
+  const int e_k8_begin = (src).k8_begin, e_k8_end = (src).k8_end, e_ld_k8 = (src).ld_k8, e_vt_fp8 = (src).vt_fp8;               \
+  const half_t* const e_res_lo = (src).res_lo;                                                                                  \
+  half_t* const e_out_lo = (src).out_lo;                                                                                        \
+  half_t* const e_out_t = (src).out_t;                                                                                          \
+  const int e_n_tr_begin = (src).n_tr_begin, e_ld_t = (src).ld_t;
+
+__device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v) {
   const float* bias = m >= g.m_split ? g.bias2 : g.bias;
-  if (bias) {
-    const f4 bv = *reinterpret_cast<const f4*>(bias + (long long)b * g.bias_bs + n);
-    v += bv;
+  const bool row_major = n < e_n_tr_begin && !(e_k8 && n >= e_k8_begin && n < e_k8_end);   // lands in `out` (not V^T / e4m3 K)
+  f4 bv = {0.f, 0.f, 0.f, 0.f};
+  h4 rv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}, rl = rv;
+  if (bias) bv = *reinterpret_cast<const f4*>(bias + (long long)b * g.bias_bs + n);
+  if (g.res && row_major) {
+    rv = *reinterpret_cast<const h4*>(g.res + (long long)m * g.ld_res + n);
+    if (e_res_lo) rl = *reinterpret_cast<const h4*>(e_res_lo + (long long)m * g.ld_res + n);
   }
-  if (n < g.col_scale_end) v *= g.col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
+  v += bv;
+  if (n < e_col_scale_end) v *= e_col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
   if (g.act == MD_ACT_SILU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = md::silu_f(v[i]);
   }
-  if (n >= g.n_tr_begin) {
+  if (n >= e_n_tr_begin) {
     // transposed store (V^T): [b][n - n_tr][tok]
     const int tok = m - b * g.tokens;
-    const int ntr = g.N - g.n_tr_begin;
-    if (g.vt_fp8) {   // e4m3 bytes (fp8 attention path)
+    const int ntr = g.N - e_n_tr_begin;
+    if (e_vt_fp8) {   // e4m3 bytes (fp8 attention path)
       int w = 0;
       w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
       w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-      unsigned char* o8 = reinterpret_cast<unsigned char*>(g.out_t) + ((long long)b * ntr + (n - g.n_tr_begin)) * g.ld_t + tok;
+      unsigned char* o8 = reinterpret_cast<unsigned char*>(e_out_t) + ((long long)b * ntr + (n - e_n_tr_begin)) * e_ld_t + tok;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o8[(long long)i * g.ld_t] = (unsigned char)((unsigned)w >> (8 * i));
+      for (int i = 0; i < 4; ++i) o8[(long long)i * e_ld_t] = (unsigned char)((unsigned)w >> (8 * i));
       return;
     }
-    half_t* o = g.out_t + ((long long)b * ntr + (n - g.n_tr_begin)) * g.ld_t + tok;
+    half_t* o = e_out_t + ((long long)b * ntr + (n - e_n_tr_begin)) * e_ld_t + tok;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[(long long)i * g.ld_t] = (half_t)v[i];
+    for (int i = 0; i < 4; ++i) o[(long long)i * e_ld_t] = (half_t)v[i];
     return;
   }
-  if (g.k8 && n >= g.k8_begin && n < g.k8_end) {   // K columns of a fused q|k|v projection as e4m3 bytes
+  if (e_k8 && n >= e_k8_begin && n < e_k8_end) {   // K columns of a fused q|k|v projection as e4m3 bytes
     int w = 0;
     w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-    *reinterpret_cast<int*>(g.k8 + (long long)m * g.ld_k8 + (n - g.k8_begin)) = w;
+    *reinterpret_cast<int*>(e_k8 + (long long)m * e_ld_k8 + (n - e_k8_begin)) = w;
     return;
   }
   if (g.res) {
-    const h4 rv = *reinterpret_cast<const h4*>(g.res + (long long)m * g.ld_res + n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
-    if (g.res_lo) {  // second term of the two-term residual stream: the chain value is res + res_lo
-      const h4 rl = *reinterpret_cast<const h4*>(g.res_lo + (long long)m * g.ld_res + n);
+    if (e_res_lo) {  // second term of the two-term residual stream: the chain value is res + res_lo
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
     }
@@ -127,11 +149,11 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, int m, int b, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
     *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
-    if (g.out_lo) {  // what the fp16 store dropped, for the next link of the residual chain
+    if (e_out_lo) {  // what the fp16 store dropped, for the next link of the residual chain
       h4 l;
 #pragma unroll
       for (int i = 0; i < 4; ++i) l[i] = (half_t)(v[i] - (float)o[i]);
-      *reinterpret_cast<h4*>(g.out_lo + (long long)m * g.ld_out + n) = l;
+      *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
     }
   }
 }
@@ -694,6 +716,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
+  const __attribute__((address_space(4))) IgemmArgs* gp = (const __attribute__((address_space(4))) IgemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(gp));   // opaque: the loads below cannot move above the k-loop
+  MD_LATE_LOAD(*gp)
   if constexpr (M32) {
     // fragment (i, j): lane holds column m = j*32 + l31 and, in registers 4q .. 4q+3, rows n = i*32 + 8q + 4 lh + (0..3)
     if constexpr (LN) {
@@ -750,7 +775,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
           if (g.splitk > 1)
             *reinterpret_cast<f4*>(g.ws + ((long long)kz * g.M + m) * g.N + n) = v;
           else
-            epi_store4(g, m, b, n, v);
+            epi_store4(g, MD_LATE_ARGS, m, b, n, v);
         }
       }
     }
@@ -815,6 +840,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     }
     return;
   }
+  if (!g.out_f32 && e_n_tr_begin >= g.N && !e_k8) {
+    // Common case (fp16 row-major output: every conv, the attention / feed-forward output projections, proj_in / proj_out): the
+    // loads of a whole column of fragments -- bias, residual, second residual term -- are issued together, on clamped addresses,
+    // before any is consumed.  (Fragment by fragment through epi_store4 the compiler emits load -> s_waitcnt vmcnt(0) -> store
+    // chains: 3 x NF x MF serial memory round trips per wave, more than the k-loop of a 5-tile GEMM.)
+    const bool has_bias = gbias != nullptr;
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + lr;
+      const int mc = min(m, Mlim - 1);
+      const int b = fast_div(mc, g.div_tok_mul, g.div_tok_sh);
+      f4 bv[NF];
+      h4 rv[NF], rl[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        bv[i] = f4{0.f, 0.f, 0.f, 0.f};
+        rv[i] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        rl[i] = rv[i];
+      }
+      if (has_bias) {   // (bias_bs == 0: the same vector for every row -- served by L1)
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          bv[i] = *reinterpret_cast<const f4*>(gbias + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+      }
+      if (g.res) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          rv[i] = *reinterpret_cast<const h4*>(g.res + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+        if (e_res_lo) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            rl[i] = *reinterpret_cast<const h4*>(e_res_lo + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (m >= Mlim) continue;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int n = n0 + wn * WTN + i * 16 + lg * 4;
+        if (n >= g.N) continue;
+        f4 v = acc[i][j];
+        v += bv[i];
+        if (n < e_col_scale_end) v *= e_col_scale;
+        if (g.act == MD_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+        }
+        if (g.res) {   // (all-zero registers when there is no second term)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
+        }
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
+        if (e_out_lo) {
+          h4 l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
+          *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int m = m0 + wm * WTM + j * 16 + lr;
@@ -824,7 +916,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     for (int i = 0; i < NF; ++i) {
       const int n = n0 + wn * WTN + i * 16 + lg * 4;
       if (n >= g.N) continue;
-      epi_store4(g, m, b, n, acc[i][j]);
+      epi_store4(g, MD_LATE_ARGS, m, b, n, acc[i][j]);
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -856,7 +948,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
     s += v1;
   }
   if (z < g.splitk) s += *reinterpret_cast<const f4*>(base + z * slab);
-  epi_store4(g, m, m / g.tokens, n, s);
+  MD_LATE_LOAD(g)
+  epi_store4(g, MD_LATE_ARGS, m, m / g.tokens, n, s);
 }
 
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64

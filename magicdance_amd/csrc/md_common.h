@@ -39,7 +39,20 @@ struct ProfScope {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (F.gelu default, ldm/modules/attention.py:50-60).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
+// <= 1e-7 |x| on the GELU -- four orders below the fp16 rounding of the result): one v_rcp + one v_exp + 8 FMAs instead of the
+// branchy ocml erff (both of its range branches execute on a diverged wave).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);   // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

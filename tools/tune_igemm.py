@@ -48,6 +48,8 @@ if os.environ.get("TUNE_ONLY_NEW"):   # keep the committed table, time only the 
         if m:
             have.add(tuple(int(v) for v in m.groups()))
     shapes = {k: v for k, v in shapes.items() if k[:6] not in have}
+if os.environ.get("TUNE_FILTER") == "linear":   # 1x1 convs / linears only (their time is mostly epilogue: re-tune after epilogue changes)
+    shapes = {k: v for k, v in shapes.items() if k[3] == 1}
 print(f"{len(shapes)} unique igemm shapes", flush=True)
 del model
 torch.cuda.empty_cache()

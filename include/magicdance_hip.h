@@ -59,7 +59,9 @@ typedef struct {
   /* epilogue */
   const float* bias;       /* fp32 [N] (or [B][bias_batch_stride]) or NULL */
   int64_t bias_batch_stride; /* 0: shared; else elements between per-sample bias vectors (time-embedding add) */
-  const void* res;         /* fp16 residual [M][ld_res] added after activation, or NULL */
+  const void* res;         /* fp16 residual [M][ld_res] added after activation, or NULL.  res / res_lo must be either disjoint
+                            * from out / out_lo or IDENTICAL to them (in-place add: same pointer, ld_res == ld_out), never a
+                            * partial overlap */
   int32_t ld_res;
   int32_t act;             /* MD_ACT_* ; GEGLU: weights/bias rows interleaved a/gate in groups of 16, out width N/2 */
   void* out;               /* fp16 (or fp32 if out_f32) [M][ld_out] */

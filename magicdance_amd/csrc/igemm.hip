@@ -846,6 +846,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     // before any is consumed.  (Fragment by fragment through epi_store4 the compiler emits load -> s_waitcnt vmcnt(0) -> store
     // chains: 3 x NF x MF serial memory round trips per wave, more than the k-loop of a 5-tile GEMM.)
     const bool has_bias = gbias != nullptr;
+    // restrict: `res` / `res_lo` are either disjoint from `out` / `out_lo` or IDENTICAL to them (in-place residual add: a lane
+    // reads exactly the elements it then writes, ordered by the data dependence) -- never partially overlapping (header contract).
+    // (Measured and dropped, same-box A/B in profiles/round2_igemm_epilogue_ab.txt: two columns in flight with unconditional
+    //  zero-page loads for absent operands -- 3-8 % slower on the epilogue-dominated GEMMs, end to end -0.4 %.)
+    const float* __restrict__ const bp = gbias;
+    const half_t* __restrict__ const resp = g.res;
+    const half_t* __restrict__ const rlp = e_res_lo;
+    half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+    half_t* __restrict__ const olp = e_out_lo;
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
       const int m = m0 + wm * WTM + j * 16 + lr;
@@ -862,16 +871,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
       if (has_bias) {   // (bias_bs == 0: the same vector for every row -- served by L1)
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          bv[i] = *reinterpret_cast<const f4*>(gbias + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
       }
-      if (g.res) {
+      if (resp) {
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          rv[i] = *reinterpret_cast<const h4*>(g.res + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
-        if (e_res_lo) {
+          rv[i] = *reinterpret_cast<const h4*>(resp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+        if (rlp) {
 #pragma unroll
           for (int i = 0; i < NF; ++i)
-            rl[i] = *reinterpret_cast<const h4*>(e_res_lo + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+            rl[i] = *reinterpret_cast<const h4*>(rlp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -887,21 +896,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
         }
-        if (g.res) {   // (all-zero registers when there is no second term)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];   // (zeros when there is no residual / no second term)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
         h4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
-        if (e_out_lo) {
+        *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
+        if (olp) {
           h4 l;
 #pragma unroll
           for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
-          *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
+          *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
         }
       }
     }

@@ -48,6 +48,8 @@ if os.environ.get("TUNE_ONLY_NEW"):   # keep the committed table, time only the 
         if m:
             have.add(tuple(int(v) for v in m.groups()))
     shapes = {k: v for k, v in shapes.items() if k[:6] not in have}
+if os.environ.get("TUNE_FILTER") == "shortk":   # K <= 640 at big M: candidates with 2 / 4 k-tiles per stage were not tried there before
+    shapes = {k: v for k, v in shapes.items() if k[2] <= 640 and k[0] > 16384}
 if os.environ.get("TUNE_FILTER") == "linear":   # 1x1 convs / linears only (their time is mostly epilogue: re-tune after epilogue changes)
     shapes = {k: v for k, v in shapes.items() if k[3] == 1}
 print(f"{len(shapes)} unique igemm shapes", flush=True)
@@ -77,9 +79,9 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     cfgs = list(range(12, 16)) if buf_ok else list(range(4, 8))  # 2-stage (vmcnt(0)) loaders only, see igemm.hip
     if buf_ok and N % 80 == 0 and act != 2:
         cfgs += [24, 25, 26, 27]   # SD-shaped tiles (BN = 80 / 160)
-    if buf_ok and M <= 16384:
+    if buf_ok and (M <= 16384 or K <= 640):   # short K: the k-loop is a handful of round trips whatever M is
         cfgs += [28] + ([29, 30, 31] if (N % 80 == 0 and act != 2) else [])   # two k-tiles per stage
-        if M <= 4096:
+        if M <= 4096 or K <= 640:
             cfgs += [32] + ([33] if (N % 80 == 0 and act != 2) else [])       # four
     ln_shape = ks == 1 and c1 == 0 and K in (320, 640, 1280) and N in (K, 3 * K, 8 * K)   # possibly a folded-LayerNorm GEMM
     if buf_ok and not ln_shape and M >= 2048:

@@ -73,8 +73,6 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
   return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
 }
 
-// Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed).  Every global load the epilogue needs (bias,
-// residual, second residual term) is ISSUED before the first one is consumed: one memory round trip per call instead of three.
 // Epilogue-only parameters.  The k-loop kernel reads them from the kernarg segment AFTER the loop (scalar loads behind an opaque
 // pointer) into plain locals: as by-value kernel arguments they would be loaded at entry and held in SGPRs across the loop, which
 // pushed the kernel over the SGPR budget (spill to scratch at entry, scratch reload at the head of every wave's epilogue); as a
@@ -93,16 +91,22 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
   half_t* const e_out_t = (src).out_t;                                                                                          \
   const int e_n_tr_begin = (src).n_tr_begin, e_ld_t = (src).ld_t;
 
-__device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v) {
+// (1) every global load the epilogue of (m, n..n+3) needs -- bias, residual, second residual term -- ISSUED together ...
+__device__ __forceinline__ void epi_load(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4& bv, h4& rv, h4& rl) {
   const float* bias = m >= g.m_split ? g.bias2 : g.bias;
   const bool row_major = n < e_n_tr_begin && !(e_k8 && n >= e_k8_begin && n < e_k8_end);   // lands in `out` (not V^T / e4m3 K)
-  f4 bv = {0.f, 0.f, 0.f, 0.f};
-  h4 rv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}, rl = rv;
+  bv = f4{0.f, 0.f, 0.f, 0.f};
+  rv = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  rl = rv;
   if (bias) bv = *reinterpret_cast<const f4*>(bias + (long long)b * g.bias_bs + n);
   if (g.res && row_major) {
     rv = *reinterpret_cast<const h4*>(g.res + (long long)m * g.ld_res + n);
     if (e_res_lo) rl = *reinterpret_cast<const h4*>(e_res_lo + (long long)m * g.ld_res + n);
   }
+}
+
+// (2) ... and consumed here: bias, column scale, activation, residual, store(s).
+__device__ __forceinline__ void epi_finish(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v, f4 bv, h4 rv, h4 rl) {
   v += bv;
   if (n < e_col_scale_end) v *= e_col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
   if (g.act == MD_ACT_SILU) {
@@ -156,6 +160,14 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, i
       *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
     }
   }
+}
+
+// Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed): one memory round trip, then the stores.
+__device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v) {
+  f4 bv;
+  h4 rv, rl;
+  epi_load(g, MD_LATE_ARGS, m, b, n, bv, rv, rl);
+  epi_finish(g, MD_LATE_ARGS, m, b, n, v, bv, rv, rl);
 }
 
 // GLDS = true: operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave
@@ -938,6 +950,13 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
   const int n = (int)(idx - (long long)m * n4) * 4;
   // all slab loads of a group of 8 are issued before any is consumed (the loop is latency-, not bandwidth-bound); the
   // summation ORDER stays z = 0, 1, 2, ... so the result does not depend on the grouping
+  MD_LATE_LOAD(g)
+  f4 ebv;   // the epilogue's own loads go out with the first slab loads (one round trip for both)
+  h4 erv, erl;
+#ifndef MD_REDUCE_PRELOAD
+#define MD_REDUCE_PRELOAD 1
+#endif
+  if (MD_REDUCE_PRELOAD) epi_load(g, MD_LATE_ARGS, m, m / g.tokens, n, ebv, erv, erl);
   const float* base = g.ws + (long long)m * g.N + n;
   const long long slab = (long long)g.M * g.N;
   f4 s = {0.f, 0.f, 0.f, 0.f};
@@ -955,8 +974,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
     s += v1;
   }
   if (z < g.splitk) s += *reinterpret_cast<const f4*>(base + z * slab);
-  MD_LATE_LOAD(g)
-  epi_store4(g, MD_LATE_ARGS, m, m / g.tokens, n, s);
+  if (!MD_REDUCE_PRELOAD) epi_load(g, MD_LATE_ARGS, m, m / g.tokens, n, ebv, erv, erl);
+  epi_finish(g, MD_LATE_ARGS, m, m / g.tokens, n, s, ebv, erv, erl);
 }
 
 // config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64

@@ -46,16 +46,32 @@ __global__ __launch_bounds__(512) void gn_stats(const GnArgs g) {
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   const int c = tx * 8;
   if (ty < g.ty) {
-#pragma unroll 4
-    for (int p = p_begin + ty; p < p_end; p += g.ty) {
-      const long long pix = (long long)b * g.hw + p;
-      const h8 v = (c < g.c0) ? *reinterpret_cast<const h8*>(g.x0 + pix * g.c0 + c)
-                              : *reinterpret_cast<const h8*>(g.x1 + pix * g.c1 + (c - g.c0));
+    // 16 pixels (16-byte vectors) per round trip: a thread owns <= 16 pixels of a 64x64 slice, so its loads all go out at once
+    // (four at a time the loop was a chain of four memory round trips)
+#ifndef MD_GN_NV
+#define MD_GN_NV 16
+#endif
+    constexpr int NV = MD_GN_NV;
+    const bool first = c < g.c0;
+    const half_t* src = first ? g.x0 + c : g.x1 + (c - g.c0);
+    const long long cs = first ? g.c0 : g.c1;
+    for (int p0 = p_begin + ty; p0 < p_end; p0 += NV * g.ty) {
+      h8 v[NV];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = (float)v[e];
-        s[e] += f;
-        ss[e] += f * f;
+      for (int u = 0; u < NV; ++u) {
+        const int p = p0 + u * g.ty;
+        if (p < p_end) v[u] = *reinterpret_cast<const h8*>(src + ((long long)b * g.hw + p) * cs);
+      }
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        if (p0 + u * g.ty < p_end) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[u][e];
+            s[e] += f;
+            ss[e] += f * f;
+          }
+        }
       }
     }
     float* r0 = red + ty * g.c + c;

@@ -54,3 +54,16 @@ x2 = torch.randn(b, 256, 1280, device=dev).to(F16)
 g2, b2 = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
 o2 = torch.empty_like(x2)
 timed(lambda: ops.groupnorm(x2, g2, b2, o2, ws, batch=b, hw=256, c0=1280, silu=True), "md_groupnorm 2 x 16x16 x 1280 (single launch)")
+
+# split-K: slabs + deterministic reduce kernel (the 16x16 / 8x8 levels of a one-frame step)
+ws = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
+for (bb, hh, cin, nn, cfg, sp) in ((2, 16, 1280, 1280, 25, 16), (3, 8, 1280, 1280, 28, 8)):
+    xs = torch.randn(bb, hh * hh, cin, device=dev).to(F16)
+    wsk = (torch.randn(nn, 9 * cin, device=dev) * 0.01).to(F16)
+    ys = torch.empty(bb, hh * hh, nn, dtype=F16, device=dev)
+    ylo = torch.empty_like(ys)
+    rs = torch.randn(bb, hh * hh, nn, device=dev).to(F16)
+    bs = torch.randn(nn, device=dev)
+    timed(lambda: ops.igemm(xs, wsk, nn, batch=bb, hin=hh, win=hh, hout=hh, wout=hh, c0=cin, ksize=3, bias=bs, res=rs, ld_res=nn, res_lo=rs,
+                            out=ys, out_lo=ylo, ws=ws, force_cfg=cfg, force_splitk=sp),
+          f"md_igemm 3x3 M={bb * hh * hh} N={nn} K={9 * cin} split {sp} + reduce (two-term residual)")

@@ -215,8 +215,10 @@ def main():
                 traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), cand
                 # the counters were collected on a launch mix with more (smaller) igemm launches per batch (pose ControlNet on its
                 # own stream): same bytes per batch, re-expressed per launch of THIS run's mix
-                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"] and args.ddim_steps == 50 and fpg == 1:
+                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"]:
                     traffic = traffic * pmc["igemm_launches_per_batch"] / ig["launches"]
+                if not (args.ddim_steps == 50 and fpg == 1 and args.size == 64 and not args.sequence):
+                    traffic, traffic_src = None, None   # the counters were collected on configs[1] only
                 break
             except Exception:  # noqa: BLE001
                 pass
@@ -229,7 +231,8 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one batch: reference-KV table pass + "
                            f"{ig['ddim_steps']} DDIM steps" + ("" if args.no_decode else " + first-stage decode") + ")", "achieved": ach,
                            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
-                           "traffic_unit": f"bytes/launch (PMC, profiles/{traffic_src})",
+                           "traffic_unit": (f"bytes/launch (PMC, profiles/{traffic_src})" if traffic_src else
+                                            "null: the PMC passes (profiles/round2_pmc_summary.json) cover configs[1] only"),
                            "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
                            "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,

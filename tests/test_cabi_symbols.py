@@ -68,3 +68,26 @@ def test_launchers_reject_bad_arguments_without_a_gpu(lib_path):
     assert lib.md_attention(ctypes.byref(a), None) == -1
     assert lib.md_layernorm(None, None, None, None, 4, 320, 1e-5, None) == -1
     assert lib.md_groupnorm_workspace_bytes(2, 4096, 32) > 0
+
+
+def test_param_structs_match_header_offsets(tmp_path):
+    """byte layout, not just field names: compile the header with gcc and compare sizeof / offsetof of every field of the three
+    parameter structs with the ctypes mirrors (a type slip -- int32 vs int64, pointer vs int -- would keep the names in order)."""
+    from magicdance_amd import _lib
+    structs = (("md_igemm_params", _lib.IgemmParams), ("md_attention_params", _lib.AttentionParams),
+               ("md_groupnorm_params", _lib.GroupNormParams))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in structs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"

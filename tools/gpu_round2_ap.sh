@@ -1,0 +1,4 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "astat" 2>&1 | tail -15

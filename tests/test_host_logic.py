@@ -309,3 +309,42 @@ def test_merged_pose_pass_matches_separate_pose_pass(monkeypatch):
     assert per_step_set2 >= 20
     assert _rel(zs["1"], g["z"]) <= 2e-2
     assert _rel(zs["1"], zs["0"]) <= 5e-3
+
+
+def test_fused_step_launch_structure(monkeypatch):
+    """Launch structure of ONE fused DDIM step (what the captured graph replays), counted as C-ABI calls on the emulated ABI: the
+    merged pass must not grow back -- 207 md_igemm (on the GPU ~45 of them add a split-K reduce kernel), 32 md_attention, 61
+    md_groupnorm, 11 small ops = the ~310 launches per step of DESIGN.md / profiles/round2_step_breakdown_1frame.txt -- and the
+    forked-stream form keeps the ControlNet's own ~110."""
+    hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
+    from magicdance_amd import ops
+    g = H.load_golden("small_b1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
+                              image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    names = ["igemm", "attention", "groupnorm", "layernorm", "add_f16", "nchw_to_nhwc_f16", "select_row_f32", "gather_rows",
+             "ddim_update", "counter_add"]
+    counts = {}
+    for n in names:
+        orig = getattr(ops, n)
+
+        def wrap(*a, _o=orig, _n=n, **kw):
+            counts[_n] = counts.get(_n, 0) + 1
+            return _o(*a, **kw)
+        monkeypatch.setattr(ops, n, wrap)
+    per_mode = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MD_MERGE_POSE", merge)
+        model._fused = None
+        model.sample_log(cond=inp["c"], batch_size=1, ddim=True, ddim_steps=4, eta=0.0, unconditional_guidance_scale=7,
+                         unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"])
+        st = model._fused
+        assert st is not None and st.table_mode
+        counts.clear()
+        st._launch_sequence()
+        per_mode[merge] = dict(counts)
+    m, f = per_mode["1"], per_mode["0"]
+    small = lambda d: sum(d.get(k, 0) for k in ("add_f16", "nchw_to_nhwc_f16", "select_row_f32", "gather_rows", "ddim_update", "counter_add"))  # noqa: E731
+    assert (m["igemm"], m["attention"], m["groupnorm"], m.get("layernorm", 0), small(m)) == (207, 32, 61, 0, 11), m
+    assert f["igemm"] - m["igemm"] >= 60 and f["groupnorm"] - m["groupnorm"] >= 20 and f["attention"] - m["attention"] >= 5, (m, f)

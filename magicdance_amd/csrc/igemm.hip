@@ -191,7 +191,11 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, i
 // chunk ^ ((row >> 1) & 7) -- a 16-lane ds_read_b128 group of the 32-row fragment read holds rows {0-3, 12-15, 20-27} (or
 // {4-11, 16-19, 28-31}); rows of equal parity share a 128-byte half of the 256-byte bank window, and (row >> 1) & 7 is distinct
 // over each group's same-parity rows, so the reads are conflict-free (row & 7, the 16-row form's swizzle, would be 2-way).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false>
+// KS1 = true: the launcher guarantees a 1x1 / linear layer on ONE source (ksize 1, stride 1, no upsample, c1 == 0): the per-tile
+// LDS-DMA issue then needs no tap / source / validity arithmetic at all -- row offsets are constants, the k offset is 128 bytes per
+// tile.  (The generic issue block is ~250 instructions per iteration of the 64x80 two-tile stage, about a third of an iteration
+// of the latency-bound one-frame GEMMs: the next stage's loads leave that much later.)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false, bool KS1 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
   constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
@@ -353,6 +357,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   auto fetch_tile = [&](int stage, bool tile_valid = true) {  // loads the tile at (k_cur, tap, cc), then advances
     char* As = smem + stage * STAGE_BYTES;
     char* Ws = As + BM * 128;
+    if constexpr (BUF && KS1) {
+      const bool kvalid = tile_valid && kt_i < g.nk;
+      const unsigned soff1 = (unsigned)kt_i * 128u;   // k-tile kt_i = channels 64 kt_i .. of the only tap of the only source
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16,
+                                                 kvalid ? rowbase0[j] : OOB, soff1, 0, 0);
+      if (skip_w_once) {
+        skip_w_once = false;
+      } else {
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+          if (W_TAIL && j == WJ - 1 && wave >= 2) break;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
+                                                   kvalid ? w_off[j] : OOB, soff1, 0, 0);
+        }
+      }
+      ++kt_i;
+      return;
+    }
     if constexpr (BUF) {
       const bool kvalid = tile_valid && kt_i < g.nk;  // uniform (K % 64 == 0 here)
       const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
@@ -1010,7 +1034,7 @@ int g_default_loader = [] {
   return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
 }();
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false>
+template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false, bool KS1 = false>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 128;
   static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
@@ -1018,13 +1042,13 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32, KS1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32, KS1>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -1032,7 +1056,10 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
 // the 2-stage buffer-loader tiles exist with and without the folded LayerNorm
 template <int BM, int BN, int WMv, int WNv, int KT = 1>
 int launch_buf2(const IgemmArgs& g, hipStream_t s) {
-  return g.ln_s1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, true, KT>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT>(g, s);
+  // the folded LayerNorm exists for 1x1 / linear layers only (validate()): always the KS1 issue path; others: KS1 when it applies
+  if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, 2, true, KT, false, true>(g, s);
+  const bool ks1 = g.ksize == 1 && g.stride == 1 && !g.ups && g.c1 == 0;
+  return ks1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT, false, true>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT>(g, s);
 }
 // 32x32x16-fragment tiles (2-stage buffer loader)
 template <int BM, int BN, int WMv, int WNv>

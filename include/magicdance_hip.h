@@ -119,6 +119,19 @@ typedef struct {
   const float* ln2_s1;
   const float* ln2_s0;
   int32_t batch2;
+  /* GroupNorm partial statistics from the epilogue (ABI v4) -- the "conv + GroupNorm" fusion of the ResBlock (openaimodel.py:221-225,
+   * 245-252; util.py:252-254): gn_part (fp32 [M / 64][2][N], may be NULL) receives, per 64-row granule g and output column n,
+   * gn_part[(2 g) * N + n] = sum and gn_part[(2 g + 1) * N + n] = sum of squares of the fp16 values this call stores in rows
+   * 64 g .. 64 g + 63 of `out`, so that the md_groupnorm which consumes `out` needs no statistics pass of its own
+   * (md_groupnorm_params.part0 / part1).  Requires the plain fp16 row-major epilogue (no out_f32 / GEGLU / transposed / e4m3
+   * columns), hout * wout % 64 == 0 (a granule never straddles two samples) and no split-K (the launcher then keeps K in one
+   * workgroup; force_splitk > 1 is refused).  Only the rows this call writes get partials (a zero-conv adding into the first
+   * samples of a tensor refreshes exactly their granules). */
+  void* gn_part;
+  /* k-groups per workgroup (ABI v4): 0 auto (tuned table / rule), else 1, 2 or 4 -- the K dimension of ONE output tile is shared
+   * by 2 or 4 four-wave groups of the same workgroup, each with its own LDS stages, and their accumulators are summed through LDS
+   * in fixed order before the epilogue (deterministic; no workspace, no second launch).  Combines with split-K. */
+  int32_t force_kg;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
@@ -171,9 +184,16 @@ typedef struct {
   void* ws; int64_t ws_bytes;
   const float* gamma2; const float* beta2;          /* ABI v3: samples b >= batch2 use this affine pair (see md_igemm batch2) */
   int32_t batch2;                                   /* <= 0 or gamma2 == NULL: one parameter set */
+  /* ABI v4: partial statistics of x0 / x1 as written by the md_igemm calls that produced them (md_igemm_params.gn_part: fp32
+   * [batch * hw / 64][2][c0 or c1]).  When given for every source (and hw % 64 == 0) the statistics pass over x is skipped: one
+   * launch folds the partials of its (sample, groups) in fixed order and normalises.  NULL: statistics are computed from x. */
+  const float* part0; const float* part1;
 } md_groupnorm_params;
 int md_groupnorm(const md_groupnorm_params* p, void* stream);
 int64_t md_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);
+/* 1 when md_groupnorm on this geometry would run a separate statistics pass over x (large slices), i.e. when partials from the
+ * producing md_igemm save a launch and a read of x; 0 when the single-launch small-slice kernel is used anyway. */
+int md_groupnorm_wants_partials(int32_t batch, int32_t hw, int32_t c, int32_t groups);
 
 /* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 2048), fp32 statistics, eps 1e-5.
  * Replaces nn.LayerNorm norm1/2/3 (ldm/modules/attention.py:270-272, 281-319). */

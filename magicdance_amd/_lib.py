@@ -28,6 +28,7 @@ class IgemmParams(C.Structure):
         ("col_scale", C.c_float), ("col_scale_end", C.c_int32), ("k8", C.c_void_p), ("k8_begin", C.c_int32),
         ("k8_end", C.c_int32), ("ld_k8", C.c_int32), ("vt_fp8", C.c_int32),
         ("w2", C.c_void_p), ("bias2", C.c_void_p), ("ln2_s1", C.c_void_p), ("ln2_s0", C.c_void_p), ("batch2", C.c_int32),
+        ("gn_part", C.c_void_p), ("force_kg", C.c_int32),
     ]
 
 
@@ -51,6 +52,7 @@ class GroupNormParams(C.Structure):
         ("hw", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("silu", C.c_int32), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("gamma2", C.c_void_p), ("beta2", C.c_void_p), ("batch2", C.c_int32),
+        ("part0", C.c_void_p), ("part1", C.c_void_p),
     ]
 
 
@@ -65,6 +67,7 @@ SIGNATURES = {
     "md_attention": (C.c_int, [C.POINTER(AttentionParams), _vp]),
     "md_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), _vp]),
     "md_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "md_groupnorm_wants_partials": (C.c_int, [_i32, _i32, _i32, _i32]),
     "md_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "md_nchw_to_nhwc_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "md_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),

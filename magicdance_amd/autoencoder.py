@@ -242,7 +242,10 @@ class VaeEngine:
             buf = _WS[key] = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         return buf
 
-    def conv(self, x, cv, *, stride=1, ups=0, asym=False, res=None, out_f32=False):
+    def conv(self, x, cv, *, stride=1, ups=0, asym=False, res=None, out_f32=False, stats=True):
+        """``stats``: let the epilogue write the GroupNorm partial statistics of the output (Act.part) where the GroupNorm that may
+        consume it would otherwise run its own statistics pass (engine.NetEngine.want_part)."""
+        from .engine import NetEngine
         n, k = cv["cout"], cv["k"]
         if ups:
             ho, wo = 2 * x.h, 2 * x.w
@@ -251,21 +254,25 @@ class VaeEngine:
         else:
             ho, wo = x.h, x.w
         out = self.arena.alloc((x.b, ho * wo, n), F32 if out_f32 else F16)
+        part = None
+        if stats and not out_f32 and NetEngine.want_part(x.b, ho * wo, n):
+            part = self.arena.alloc((x.b * ho * wo // 64, 2, n), F32)
         ops.igemm(x.t, cv["w"], n, batch=x.b, hin=x.h, win=x.w, hout=ho, wout=wo, c0=x.c, ksize=k, stride=stride, ups=ups,
                   bias=cv["b"], res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=MD_ACT_NONE,
-                  out=out, ld_out=n, out_f32=out_f32, ws=self._ws(), asym_pad=asym)
-        return Act(out, x.b, ho, wo, n)
+                  out=out, ld_out=n, out_f32=out_f32, ws=self._ws(), asym_pad=asym, gn_part=part)
+        return Act(out, x.b, ho, wo, n, None, part)
 
     def gn(self, x, gb, silu=True):
         out = self.arena.alloc((x.b, x.hw, x.c), F16)
-        ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, groups=32, eps=1e-6, silu=silu)
+        ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, groups=32, eps=1e-6, silu=silu,
+                      part0=x.part)
         return Act(out, x.b, x.h, x.w, x.c)
 
     def resblock(self, r, x):
         h = self.gn(x, r["gn1"])
         h = self.conv(h, dict(w=r["conv1_w"], b=r["conv1_b"], cout=r["cout"], k=3))
         h = self.gn(h, r["gn2"])
-        skip = self.conv(x, dict(w=r["skip_w"], b=r["skip_b"], cout=r["cout"], k=1)) if "skip_w" in r else x
+        skip = self.conv(x, dict(w=r["skip_w"], b=r["skip_b"], cout=r["cout"], k=1), stats=False) if "skip_w" in r else x
         return self.conv(h, dict(w=r["conv2_w"], b=r["conv2_b"], cout=r["cout"], k=3), res=skip)
 
     def attnblock(self, a, x):

@@ -5,12 +5,12 @@
 //   m = (b, oy, ox)   k = tap*(c0+c1) + c   A gathered on the fly from one or two NHWC sources (channel concat),
 //                                            with zero padding, stride 2 and nearest x2 upsample folded in the gather.
 //
-// Tile: BM x BN x 64, 256 threads = 4 waves (WAVES_M x WAVES_N), v_mfma_f32_16x16x32_f16.  LDS holds two stages of
-// [BM][64] + [BN][64] fp16 with a 16-byte-chunk XOR swizzle (chunk ^= row & 7) so the fragment ds_read_b128 of 16
-// consecutive rows is at most 2-way conflicted.  Global->register->LDS staging (the gather needs per-lane predication),
-// next tile's global loads are issued before the current tile's MFMAs, one barrier per k-tile.
-// Small-M layers (8x8 / 16x16 latents) are weight-streaming bound: split-K over blockIdx.z with fp32 slabs and a
-// deterministic reduce kernel that applies the same epilogue.
+// Tile: BM x BN x 64 per k-group of 4 waves (WAVES_M x WAVES_N), v_mfma_f32_16x16x32_f16.  LDS holds, per k-group, two stages of
+// KT x ([BM][64] + [BN][64]) fp16 filled by LDS-DMA, with a 16-byte-chunk XOR swizzle (chunk ^= row & 7) applied to the SOURCE
+// chunk so the fragment ds_read_b128 of 16 consecutive rows is conflict-free.  One vmcnt(0) + barrier per stage.
+// Small-M layers (8x8 / 16x16 / 32x32 latents of a one-frame step) have too few output tiles for 256 CUs: their K dimension is
+// split (a) across the 1 / 2 / 4 k-groups of one workgroup, combined through LDS, and (b) beyond that over blockIdx.z with fp32
+// slabs and a deterministic reduce kernel that applies the same epilogue.
 //
 // Reference arithmetic replaced: see include/magicdance_hip.h (md_igemm).
 #include <cstdio>
@@ -64,8 +64,7 @@ struct IgemmArgs {
   const float* ln2_s1;
   const float* ln2_s0;
   int m_split, tiles_m1;
-  int early_w;  // MD_IGEMM_EARLY_W (default 1): first-tile W loads ahead of the row setup
-  int dbg;  // MD_IGEMM_DEBUG bit mask (component timing only, results are garbage): 1 no MFMA, 2 no LDS reads + MFMA, 4 no k-loop loads
+  float* part;   // GroupNorm partial statistics [M / 64][2][N] (sum | sum of squares of the stored fp16 values), or nullptr
 };
 
 // n / d for n < 2^24: q = (n * mul) >> sh with mul = floor(2^sh / d) + 1, sh = 24 + ceil(log2 d) (host side below)
@@ -170,61 +169,69 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, i
   epi_finish(g, MD_LATE_ARGS, m, b, n, v, bv, rv, rl);
 }
 
-// GLDS = true: operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave
-// instruction, no VGPR round trip, no ds_write); the LDS image is lane-linear, so the XOR swizzle is applied to the
-// per-lane SOURCE chunk instead (lane (r, c) fetches global chunk c ^ (r & 7)); padding / k-tails read md_zero_page.
-// Address generation is branch-free: per row a 9-bit tap-validity mask and the (y, x) of tap (0,0) are computed once;
-// per k-tile a thread derives (tap, channel) of ITS fixed 16-byte k-chunk incrementally and selects pointer-or-zero.
-// LOADER 2 replaces the 64-bit pointer arithmetic + zero page by raw buffer loads: three wave-uniform descriptors
-// (a0, a1, w), per-lane 32-bit byte offsets built from 24-bit multiplies, and "out of image / past K" expressed as an
-// out-of-range offset, which the hardware turns into zeros in LDS.  (The k-tile loop was VALU-bound on address
-// generation with the pointer forms: ~900 VALU cycles vs ~540 MFMA cycles per 128x128x64 tile.)
-// STAGES > 2 (GLDS only; NOT used by the tuned table / defaults: counted vmcnt proved unreliable next to DMA instructions
-// whose lanes are all out of range -- see attention.hip -- and bought < 3 %): software pipeline with STAGES-1 k-tiles of LDS-DMA in flight.  A k-tile iteration is
-// latency-bound otherwise (~1.2 us per 64-deep tile measured with one tile of prefetch, vs ~0.1-0.2 us of MFMA work), so
-// the loop uses counted `s_waitcnt vmcnt(N)` + a raw s_barrier (a __syncthreads() would drain the DMA queue to 0):
-//   wait until only (STAGES-2) tiles are outstanding -> barrier -> refill the stage freed by the previous iteration ->
-//   MFMAs on the landed stage.  Tiles past the end are fetched from the zero page so the outstanding count is constant.
-// M32 = true: v_mfma_f32_32x32x16_f16 fragments (a wave tile is MF32 x NF32 fragments of 32 x 32).  Register-only loops of the
-// 16x16x32 form sustain 1.3-1.6 PFLOP/s on this chip, 32x32x16 chains 2.15-2.23 (profiles/round2_mfma_issue_rate.txt); the
-// operand bytes read from LDS per MFMA are the same (one ds_read_b128 per lane and operand), per flop half.  LDS swizzle:
-// chunk ^ ((row >> 1) & 7) -- a 16-lane ds_read_b128 group of the 32-row fragment read holds rows {0-3, 12-15, 20-27} (or
-// {4-11, 16-19, 28-31}); rows of equal parity share a 128-byte half of the 256-byte bank window, and (row >> 1) & 7 is distinct
-// over each group's same-parity rows, so the reads are conflict-free (row & 7, the 16-row form's swizzle, would be 2-way).
+// 16-lane (one DPP row = the 16 lr lanes that share lg) sum, fixed order -> deterministic: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror.  Every lane of the row ends up with the row's sum.
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+#endif
+  return v;
+}
+
+// Operands go global -> LDS directly (LDS-DMA, 1 KiB = 8 rows x 128 B per wave instruction, no VGPR round trip, no ds_write); the
+// LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk instead (lane (r, c) fetches global chunk
+// c ^ (r & 7)).
+// LOADER 1 (ragged channel counts: the stem, the hint encoder, the VAE's 3 / 4-channel ends): global_load_lds with per-lane 64-bit
+// pointers, padding / k-tails read md_zero_page.  Address generation is branch-free: per row a 9-bit tap-validity mask and the
+// (y, x) of tap (0,0) are computed once; per k-tile a thread derives (tap, channel) of ITS fixed 16-byte k-chunk incrementally
+// and selects pointer-or-zero.
+// LOADER 2 (every layer whose sources are multiples of 64 channels): raw buffer loads -- three wave-uniform descriptors (a0, a1,
+// w), per-lane 32-bit byte offsets, "out of image / past K" expressed as an out-of-range offset, which the hardware turns into
+// zeros in LDS; tap / source / channel base of a 64-channel k-tile are wave-uniform scalars.
+// KT = 64-deep k-tiles per pipeline stage (two stages): one vmcnt(0) + barrier round trip fetches KT k-tiles -- the k-loop of a
+// small GEMM on cold weights is one HBM round trip per iteration.
 // KS1 = true: the launcher guarantees a 1x1 / linear layer on ONE source (ksize 1, stride 1, no upsample, c1 == 0): the per-tile
-// LDS-DMA issue then needs no tap / source / validity arithmetic at all -- row offsets are constants, the k offset is 128 bytes per
-// tile.  (The generic issue block is ~250 instructions per iteration of the 64x80 two-tile stage, about a third of an iteration
-// of the latency-bound one-frame GEMMs: the next stage's loads leave that much later.)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false, bool KS1 = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
+// LDS-DMA issue needs no tap / source / validity arithmetic at all -- row offsets are constants, the k offset is 128 bytes per tile.
+// KG = k-groups per workgroup (round 3): the workgroup has 4 KG waves; group kg = wave / 4 runs the 2-stage loop above on the
+// k-tiles kt_begin + kg, + kg + KG, ... of THE SAME output tile in its own LDS stages (one barrier serves all groups), and the
+// groups' fp32 accumulators are summed through LDS in fixed order before the epilogue.  This is split-K without slabs, reduce
+// kernel or a second launch: a one-frame layer has too few output tiles to fill 256 CUs with more than one 4-wave workgroup
+// each, so its k-loop was a chain of L2 / HBM round trips with 4 waves per CU to hide them -- with KG = 4 a CU has four k-tiles
+// in flight and four waves per SIMD issuing MFMAs for the same tile.
+// GroupNorm partial statistics (g.part != nullptr, common fp16 epilogue only): per 64-row granule and output column the sum and
+// the sum of squares of the fp16 values just stored, so that the GroupNorm that consumes this tensor needs no statistics pass.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, bool LN = false, int KT = 1, bool KS1 = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
-  constexpr bool GLDS = LOADER >= 1;   // operands go straight to LDS (LDS-DMA)
   constexpr bool BUF = LOADER == 2;    // buffer_load ... lds with hardware out-of-range -> 0 and 32-bit offsets
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  static_assert(STAGES == 2 || GLDS, "deep pipeline needs the direct-to-LDS loader");
-  static_assert(!LN || (LOADER == 2 && STAGES == 2), "LayerNorm folding is instantiated for the 2-stage buffer loader");
+  static_assert(LOADER == 1 || LOADER == 2, "LDS-DMA loaders only");
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per k-group");
+  static_assert(!LN || BUF, "LayerNorm folding is instantiated for the buffer loader");
+  static_assert(KG == 1 || BUF, "k-groups exist for the buffer loader");
+  static_assert(!KS1 || BUF, "KS1 is a buffer-loader issue path");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int AJ = BM / 32, WJ = (BN + 31) / 32;  // 16-byte chunks per thread per k-tile
   // BN % 32 == 16 (the 80-wide SD tiles): the last W pass covers 16 rows = waves 0 and 1 only (a wave serves 8 rows)
   constexpr bool W_TAIL = (BN % 32) != 0;
-  static_assert(!W_TAIL || LOADER == 2, "ragged BN is implemented for the buffer loader only");
-  static_assert(BM % 32 == 0 && BN % 16 == 0, "tile shape");
-  static_assert(!M32 || (LOADER == 2 && STAGES == 2 && KT == 1 && WTM % 32 == 0 && WTN % 32 == 0), "32x32 fragments: 2-stage buffer loader tiles");
-  constexpr int MF32 = WTM / 32, NF32 = WTN / 32;
-  typedef float f16v __attribute__((ext_vector_type(16)));
-  // KT = 64-deep k-tiles per pipeline stage.  KT = 2 (small tiles, 2-stage buffer loader): one vmcnt(0)+barrier round trip
-  // fetches two k-tiles -- the k-loop of a small GEMM on cold weights is one HBM round trip per iteration, so twice the
-  // bytes per trip halves its length.  LDS addressing is by SLOT = stage * KT + sub-tile.
+  static_assert(!W_TAIL || BUF, "ragged BN is implemented for the buffer loader only");
+  static_assert(BM % 32 == 0 && BN % 16 == 0 && WTM <= 64, "tile shape");
   constexpr int STAGE_BYTES = (BM + BN) * 128;   // bytes of ONE k-tile slot
-  static_assert(KT == 1 || (LOADER == 2 && STAGES == 2), "multi-tile stages exist for the 2-stage buffer loader");
+  constexpr int GROUP_BYTES = 2 * KT * STAGE_BYTES;
+  static_assert(KT == 1 || BUF, "multi-tile stages exist for the buffer loader");
+  static_assert((KG - 1) * NF * MF * 4096 + (LN ? (KG - 1) * MF * 2 * 1024 : 0) <= KG * GROUP_BYTES, "cross-group reduction fits the stage memory");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x & 255;   // thread within its k-group
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave within the group
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // k-group of this wave
   const int lr = lane & 15, lg = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+  char* const gsm = smem + kg * GROUP_BYTES;   // this group's stages
 
   // XCD-aware bijective remap: consecutive logical tiles (same weight panel) share one XCD's L2.
   const int nwg = g.tiles_m * g.tiles_n;
@@ -247,6 +254,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   const int kz = blockIdx.z;
   const int kt_begin = kz * g.tiles_per_split;
   const int kt_end = min(g.nk, kt_begin + g.tiles_per_split);
+  // k-tiles of this group: kt_first, kt_first + KG, ... < kt_end; every group runs the loop of group 0 (the longest)
+  const int kt_first = kt_begin + kg;
+  const int n_mine = kt_first < kt_end ? (kt_end - kt_first + KG - 1) / KG : 0;
+  const int n_max = kt_begin < kt_end ? (kt_end - kt_begin + KG - 1) / KG : 0;
   // parameter set of this tile
   const half_t* const gw = set2 ? g.w2 : g.w;
   [[maybe_unused]] const float* const gbias = set2 ? g.bias2 : g.bias;
@@ -256,26 +267,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   // ---- loader role: LDS slot (row, lc) for rows lrow + 32 j; fixed global k-chunk gc -------------------------
   const int lc = tid & 7, lrow = tid >> 3;
   // source chunk held at LDS position lc of this thread's rows (lrow + 32 j: the swizzle key is the same for all of them)
-  const int gc = lc ^ (M32 ? ((lrow >> 1) & 7) : (lrow & 7));
+  const int gc = lc ^ (lrow & 7);
   const int ups = g.ups;           // 0 / 1: source coordinate = virtual coordinate >> ups
-  // 2-stage buffer loader: the W part of the FIRST k-tile depends on nothing computed below, so its LDS-DMA is issued
-  // before the per-row im2col setup (a few hundred VALU): the HBM latency of the layer's cold weights overlaps it
+  // buffer loader: the W part of the FIRST k-tile depends on nothing computed below, so its LDS-DMA is issued before the per-row
+  // im2col setup (a few hundred VALU): the HBM latency of the layer's cold weights overlaps it
   [[maybe_unused]] bool skip_w_once = false;
-  if constexpr (LOADER == 2 && STAGES == 2) {
-    if (kt_begin < kt_end && g.early_w) {
-      int tap0 = 0, cc0 = kt_begin * 64;
+  if constexpr (BUF) {
+    if (n_mine > 0) {
+      int tap0 = 0, cc0 = kt_first * 64;
       if (g.ksize == 3) {
-        const int cb = kt_begin / 9;
-        tap0 = kt_begin - cb * 9;
+        const int cb = kt_first / 9;
+        tap0 = kt_first - cb * 9;
         cc0 = cb * 64;
       }
       const unsigned ksoff0 = (unsigned)(tap0 * g.cin + cc0) * 2u;
       const __amdgpu_buffer_rsrc_t rs_w0 =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
-      char* Ws0 = smem + BM * 128;
+      char* Ws0 = gsm + BM * 128;
 #pragma unroll
-      for (int j = 0; j < (BN + 31) / 32; ++j) {
-        if ((BN % 32) != 0 && j == (BN + 31) / 32 - 1 && wave >= 2) break;
+      for (int j = 0; j < WJ; ++j) {
+        if (W_TAIL && j == WJ - 1 && wave >= 2) break;
         const unsigned wo = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u + (unsigned)gc * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0, (__attribute__((address_space(3))) void*)(Ws0 + (32 * j + 8 * wave) * 128),
                                                  16, wo, ksoff0, 0, 0);
@@ -306,19 +317,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     }
     a_mask[j] = mask;
   }
-  const half_t* w_ptr[WJ];
+  [[maybe_unused]] const half_t* w_ptr[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; ++j) w_ptr[j] = gw + (long long)min(n0 + lrow + 32 * j, g.N - 1) * g.K;
-  const half_t* zero = reinterpret_cast<const half_t*>(md_zero_page);
+  [[maybe_unused]] const half_t* zero = reinterpret_cast<const half_t*>(md_zero_page);
 
-  // (tap, channel) of this thread's k-chunk, advanced by 64 channels per k-tile
-  int k_cur = kt_begin * 64 + gc * 8;
-  int tap = 0, cc = k_cur;
-  if (g.ksize == 3) {
+  // LOADER 1: (tap, channel) of this thread's k-chunk, advanced by 64 channels per k-tile
+  [[maybe_unused]] int k_cur = kt_begin * 64 + gc * 8;
+  [[maybe_unused]] int tap = 0, cc = k_cur;
+  if (!BUF && g.ksize == 3) {
     tap = k_cur / g.cin;
     cc = k_cur - tap * g.cin;
   }
-  h8 ra[AJ], rw[WJ];
   // ---- BUF loader state: per-row byte offsets of the tap-centre pixel (+ this thread's chunk) in either source, relative
   // to descriptors whose base is shifted back by pad*(win+1) pixels so that every tap offset is >= 0.  Per k-tile the
   // address of row j is  rowbase[j] (VGPR, constant)  +  soffset (SGPR: tap, channel base)  -> no per-tile address VALU
@@ -334,12 +344,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     rowbase1[j] = centre * (unsigned)g.c1 * 2u + (unsigned)gc * 16u;
   }
   const int shift_pix = ups ? 0 : g.pad * (g.win + 1);
-  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<half_t*>(g.a0) - (long long)shift_pix * g.c0, 0, (g.batch * g.hin * g.win + shift_pix) * g.c0 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<half_t*>(g.a1 ? g.a1 : g.a0) - (long long)shift_pix * (g.a1 ? g.c1 : g.c0), 0,
       (g.batch * g.hin * g.win + shift_pix) * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;  // beyond any tensor: the load returns zeros
 
   // BUF loader: the launcher guarantees cin % 64 == 0 and c0 % 64 == 0, so a 64-channel k-tile lies in ONE tap of ONE
@@ -348,244 +358,146 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
   // taps of one 64-channel block re-read the same (BM + halo) pixels x 128 B, so the A operand is served from L1/L2 instead
   // of being re-streamed from the Infinity Cache nine times per pass (the tap-outer order had a reuse distance of a whole
   // Cin sweep, ~BM*Cin*2 B per workgroup, x 64 resident workgroups per XCD >> the 4 MB L2).  W's k offset follows.
-  int kt_i = kt_begin, tap_u = 0, cc_u = kt_begin * 64;
+  // A group's tile sequence advances by KG tiles per fetch.
+  int kt_i = kt_first, tap_u = 0, cc_u = kt_first * 64;
   if (g.ksize == 3) {
-    const int cb = kt_begin / 9;
-    tap_u = kt_begin - cb * 9;
+    const int cb = kt_first / 9;
+    tap_u = kt_first - cb * 9;
     cc_u = cb * 64;
   }
-  auto fetch_tile = [&](int stage, bool tile_valid = true) {  // loads the tile at (k_cur, tap, cc), then advances
-    char* As = smem + stage * STAGE_BYTES;
+  auto fetch_tile = [&](int slot) {  // loads this group's next tile (if it has one) into ``slot``, then advances
+    char* As = gsm + slot * STAGE_BYTES;
     char* Ws = As + BM * 128;
-    if constexpr (BUF && KS1) {
-      const bool kvalid = tile_valid && kt_i < g.nk;
-      const unsigned soff1 = (unsigned)kt_i * 128u;   // k-tile kt_i = channels 64 kt_i .. of the only tap of the only source
-#pragma unroll
-      for (int j = 0; j < AJ; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16,
-                                                 kvalid ? rowbase0[j] : OOB, soff1, 0, 0);
-      if (skip_w_once) {
-        skip_w_once = false;
-      } else {
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-          if (W_TAIL && j == WJ - 1 && wave >= 2) break;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
-                                                   kvalid ? w_off[j] : OOB, soff1, 0, 0);
-        }
-      }
-      ++kt_i;
-      return;
-    }
     if constexpr (BUF) {
-      const bool kvalid = tile_valid && kt_i < g.nk;  // uniform (K % 64 == 0 here)
-      const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
-      const bool second = cc_u >= g.c0;
-      const unsigned cs = second ? g.c1 : g.c0;
-      const unsigned cbase = (unsigned)(second ? cc_u - g.c0 : cc_u);
-      const int tapbit = kvalid ? (1 << tap_u) : 0;
-      unsigned voff[AJ];
-      unsigned soff = 0;
-      if (ups) {  // nearest x2 upsample: the source pixel is not affine in the tap -> full per-lane offset
+      const bool kvalid = kt_i < kt_end;  // uniform (K % 64 == 0 here)
+      if (kvalid) {
+        if constexpr (KS1) {
+          const unsigned soff1 = (unsigned)kt_i * 128u;   // k-tile kt_i = channels 64 kt_i .. of the only tap of the only source
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-          const int sy = (a_y[j] + dy) >> 1, sx = (a_x[j] + dx) >> 1;
-          const unsigned pix = (unsigned)(a_pix[j] + (int)__mul24(sy, g.win) + sx);
-          const unsigned v = (__umul24(pix, cs) + cbase + (unsigned)gc * 8u) * 2u;
-          voff[j] = (a_mask[j] & tapbit) ? v : OOB;
-        }
-      } else {
-        soff = ((unsigned)(dy * g.win + dx) * cs + cbase) * 2u;
+          for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16,
+                                                     rowbase0[j], soff1, 0, 0);
+          if (skip_w_once) {
+            skip_w_once = false;
+          } else {
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) voff[j] = (a_mask[j] & tapbit) ? (second ? rowbase1[j] : rowbase0[j]) : OOB;
-      }
-      if (second) {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
-                                                   16, voff[j], soff, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
-                                                   16, voff[j], soff, 0, 0);
-      }
-      const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
-      if (skip_w_once) {
-        skip_w_once = false;  // the first tile's W part is already in flight (issued ahead of the row setup)
-      } else {
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-          if (W_TAIL && j == WJ - 1 && wave >= 2) break;  // wave-uniform: rows 32 j + 8 wave .. + 7 lie beyond BN
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
-                                                   16, kvalid ? w_off[j] : OOB, ksoff, 0, 0);
-        }
-      }
-      ++kt_i;
-      if (g.ksize == 3) {
-        if (++tap_u == 9) {
-          tap_u = 0;
-          cc_u += 64;
-        }
-      } else {
-        cc_u += 64;
-      }
-      return;
-    }
-    const bool kvalid = tile_valid && k_cur < g.K;
-    const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-    const bool second = cc >= g.c0;
-    const int cs = second ? g.c1 : g.c0;
-    const int ccc = second ? cc - g.c0 : cc;
-    {
-      const half_t* src = second ? g.a1 : g.a0;
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const int sy = (a_y[j] + dy) >> ups, sx = (a_x[j] + dx) >> ups;
-        // branch-free pointer-or-zero-page: mask the element offset, select the base
-        const long long okmask = -(long long)((kvalid ? (a_mask[j] >> tap) : 0) & 1);
-        const long long off = ((long long)(a_pix[j] + sy * g.win + sx) * cs + ccc) & okmask;
-        const half_t* p = (okmask ? src : zero) + off;
-        if constexpr (GLDS) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                           (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16, 0, 0);
+            for (int j = 0; j < WJ; ++j) {
+              if (W_TAIL && j == WJ - 1 && wave >= 2) break;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
+                                                       w_off[j], soff1, 0, 0);
+            }
+          }
         } else {
-          ra[j] = *reinterpret_cast<const h8*>(p);
-        }
-      }
+          const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
+          const bool second = cc_u >= g.c0;
+          const unsigned cs = second ? g.c1 : g.c0;
+          const unsigned cbase = (unsigned)(second ? cc_u - g.c0 : cc_u);
+          const int tapbit = 1 << tap_u;
+          unsigned voff[AJ];
+          unsigned soff = 0;
+          if (ups) {  // nearest x2 upsample: the source pixel is not affine in the tap -> full per-lane offset
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        const half_t* p = (kvalid ? w_ptr[j] : zero) + (kvalid ? k_cur : 0);
-        if constexpr (GLDS) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                           (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16, 0, 0);
-        } else {
-          rw[j] = *reinterpret_cast<const h8*>(p);
-        }
-      }
-    }
-    k_cur += 64;
-    cc += 64;
-    if (g.ksize == 3) {
-      while (cc >= g.cin) {
-        cc -= g.cin;
-        ++tap;
-      }
-    }
-  };
-  auto store_tile = [&](int stage) {  // register-staged variant only: LDS slot (row, lc) <- chunk gc
-    char* As = smem + stage * STAGE_BYTES;
-    char* Ws = As + BM * 128;
+            for (int j = 0; j < AJ; ++j) {
+              const int sy = (a_y[j] + dy) >> 1, sx = (a_x[j] + dx) >> 1;
+              const unsigned pix = (unsigned)(a_pix[j] + (int)__mul24(sy, g.win) + sx);
+              const unsigned v = (__umul24(pix, cs) + cbase + (unsigned)gc * 8u) * 2u;
+              voff[j] = (a_mask[j] & tapbit) ? v : OOB;
+            }
+          } else {
+            soff = ((unsigned)(dy * g.win + dx) * cs + cbase) * 2u;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) *reinterpret_cast<h8*>(As + (lrow + 32 * j) * 128 + (lc << 4)) = ra[j];
+            for (int j = 0; j < AJ; ++j) voff[j] = (a_mask[j] & tapbit) ? (second ? rowbase1[j] : rowbase0[j]) : OOB;
+          }
+          if (second) {
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) *reinterpret_cast<h8*>(Ws + (lrow + 32 * j) * 128 + (lc << 4)) = rw[j];
-  };
-
-  f4 acc[M32 ? 1 : NF][M32 ? 1 : MF];
-  f16v acc32[M32 ? NF32 : 1][M32 ? MF32 : 1];
-  if constexpr (M32) {
+            for (int j = 0; j < AJ; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                       16, voff[j], soff, 0, 0);
+          } else {
 #pragma unroll
-    for (int i = 0; i < NF32; ++i)
+            for (int j = 0; j < AJ; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                       16, voff[j], soff, 0, 0);
+          }
+          const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
+          if (skip_w_once) {
+            skip_w_once = false;  // the first tile's W part is already in flight (issued ahead of the row setup)
+          } else {
 #pragma unroll
-      for (int j = 0; j < MF32; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-      for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  const int l31 = lane & 31, lh = lane >> 5;   // 32x32 fragments: row / column index and k-half of this lane
-
-  // LN: per-lane partial sum / sum of squares of the A rows this lane reads as MFMA operands (row i*16+lr, k-chunks lg and
-  // 4+lg of every 64-wide tile = a quarter of K); the four lg lanes are combined after the k-loop.
-  constexpr int LNF = M32 ? MF32 : MF;
-  [[maybe_unused]] float ln_sum[LNF], ln_sq[LNF];
-  if constexpr (LN) {
-#pragma unroll
-    for (int i = 0; i < LNF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
-  }
-
-  auto no_mid = [] {};
-  auto compute_tile = [&](int stage, auto&& mid) {
-    const char* As = smem + stage * STAGE_BYTES;
-    const char* Ws = As + BM * 128;
-#ifdef MD_IGEMM_DEBUG  // component timing build (tools/igemm_parts.py): -DMD_IGEMM_DEBUG, masks from the environment
-    if (g.dbg & 2) {
-      mid();
-      return;
-    }
-    if (g.dbg & 1) {  // LDS operand reads only
-      mid();
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int chunk = ks * 4 + lg;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          const int row = wm * WTM + i * 16 + lr;
-          const h8 v = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ (row & 7)) << 4));
-          asm volatile("" ::"v"(v));
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const int row = wn * WTN + i * 16 + lr;
-          const h8 v = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ (row & 7)) << 4));
-          asm volatile("" ::"v"(v));
-        }
-      }
-      return;
-    }
-#endif
-    if constexpr (M32) {
-      // four 16-deep k-steps per 64-deep tile; lane half lh holds k = 8 lh .. 8 lh + 7 of a step.  All fragments of the tile are
-      // requested before the first MFMA (steps 0-1, then the next tile's LDS-DMA issue, then steps 2-3), as in the 16-row form.
-      h8 af[4][MF32], wf[4][NF32];
-      auto load32 = [&](int ks) {
-        const int chunk = ks * 2 + lh;
-#pragma unroll
-        for (int i = 0; i < MF32; ++i) {
-          const int row = wm * WTM + i * 32 + l31;
-          af[ks][i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < NF32; ++i) {
-          const int row = wn * WTN + i * 32 + l31;
-          wf[ks][i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-        }
-      };
-      load32(0);
-      load32(1);
-      __builtin_amdgcn_sched_barrier(0);
-      mid();
-      __builtin_amdgcn_sched_barrier(0);
-      load32(2);
-      load32(3);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if constexpr (LN) {
-          typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-          const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-          for (int i = 0; i < MF32; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
-              ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
-              ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
+            for (int j = 0; j < WJ; ++j) {
+              if (W_TAIL && j == WJ - 1 && wave >= 2) break;  // wave-uniform: rows 32 j + 8 wave .. + 7 lie beyond BN
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128),
+                                                       16, w_off[j], ksoff, 0, 0);
             }
           }
         }
-#pragma unroll
-        for (int i = 0; i < NF32; ++i)
-#pragma unroll
-          for (int j = 0; j < MF32; ++j)
-            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], af[ks][j], acc32[i][j], 0, 0, 0);
+      }
+      kt_i += KG;
+      if (g.ksize == 3) {
+        tap_u += KG;
+        if (tap_u >= 9) {
+          tap_u -= 9;
+          cc_u += 64;
+        }
+      } else {
+        cc_u += 64 * KG;
       }
       return;
+    } else {
+      const bool kvalid = kt_i < kt_end && k_cur < g.K;
+      ++kt_i;
+      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+      const bool second = cc >= g.c0;
+      const int cs = second ? g.c1 : g.c0;
+      const int ccc = second ? cc - g.c0 : cc;
+      {
+        const half_t* src = second ? g.a1 : g.a0;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+          const int sy = (a_y[j] + dy) >> ups, sx = (a_x[j] + dx) >> ups;
+          // branch-free pointer-or-zero-page: mask the element offset, select the base
+          const long long okmask = -(long long)((kvalid ? (a_mask[j] >> tap) : 0) & 1);
+          const long long off = ((long long)(a_pix[j] + sy * g.win + sx) * cs + ccc) & okmask;
+          const half_t* p = (okmask ? src : zero) + off;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                           (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+          const half_t* p = (kvalid ? w_ptr[j] : zero) + (kvalid ? k_cur : 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                           (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16, 0, 0);
+        }
+      }
+      k_cur += 64;
+      cc += 64;
+      if (g.ksize == 3) {
+        while (cc >= g.cin) {
+          cc -= g.cin;
+          ++tap;
+        }
+      }
     }
+  };
+
+  f4 acc[NF][MF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // LN: per-lane partial sum / sum of squares of the A rows this lane reads as MFMA operands (row i*16+lr, k-chunks lg and
+  // 4+lg of every 64-wide tile = a quarter of K); the four lg lanes (and the k-groups) are combined after the k-loop.
+  [[maybe_unused]] float ln_sum[MF], ln_sq[MF];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
+  }
+
+  auto no_mid = [] {};
+  auto compute_tile = [&](int slot, auto&& mid) {
+    const char* As = gsm + slot * STAGE_BYTES;
+    const char* Ws = As + BM * 128;
     // Both 32-deep k-steps of the tile: ALL operand fragments are requested from LDS before the first MFMA (the compiler, left
     // alone, keeps one ds_read_b128 in flight per pair of MFMAs -- ~70 idle MFMA cycles per pair at one or two waves per SIMD),
     // and ``mid`` (the next tile's LDS-DMA issue: address VALU + buffer_load..lds) runs while the first fragments are in flight.
@@ -632,212 +544,102 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     }
   };
 
-  if constexpr (M32) {
-    // ---- 32x32x16 fragments: software-pipelined k-loop ------------------------------------------------------------------
-    // Register-only loops of v_mfma_f32_16x16x32_f16 sustain 1.3-1.6 PFLOP/s on this chip, 32x32x16 chains 2.15-2.23
-    // (profiles/round2_mfma_issue_rate.txt): a wave cannot issue the short MFMA back to back.  With the long one the MFMA pipe is
-    // fed by ONE wave per SIMD -- if that wave never stops for LDS.  So the operand fragments are double-buffered in registers at
-    // k-step granularity: the ds_read_b128 of step s + 1 are issued before the MFMAs of step s.  The tile boundary sits before the
-    // LAST step of a tile: wait for the next tile's LDS-DMA (issued one whole tile earlier) and for this wave's last fragment
-    // reads of the current stage, barrier, re-arm the current stage with the tile after next, read the next tile's first
-    // fragments -- then the last step's MFMAs run while all of that is in flight.  Two LDS stages, always vmcnt(0).
-    static_assert(!LN, "the folded-LayerNorm GEMMs use the 16-row tiles");
-    h8 fa[2][MF32], fw[2][NF32];
-    auto rd = [&](int stage, int ks, int buf) {
-      const char* As = smem + stage * STAGE_BYTES;
-      const char* Ws = As + BM * 128;
-      const int chunk = ks * 2 + lh;
+  // ---- k-loop: two stages of KT tiles per group; iteration ``it`` computes the group's tiles it*KT .. it*KT + KT - 1 ----------
+  if (n_max > 0) {
 #pragma unroll
-      for (int i = 0; i < MF32; ++i) {
-        const int row = wm * WTM + i * 32 + l31;
-        fa[buf][i] = *reinterpret_cast<const h8*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-      }
+    for (int u = 0; u < KT; ++u) fetch_tile(u);
+  }
+  const int iters = (n_max + KT - 1) / KT;
+  for (int it = 0; it < iters; ++it) {
+    const int stage = it & 1;
+    // explicit drain of this wave's LDS-DMA: the compiler's own wait before a barrier is not reliable for
+    // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the stage's tiles have landed for every wave; every wave is done with the other stage
+    // the refill of the other stage is issued from INSIDE the first tile's compute, behind its first fragment reads
+    auto refill = [&] {
+      if (it + 1 < iters) {
 #pragma unroll
-      for (int i = 0; i < NF32; ++i) {
-        const int row = wn * WTN + i * 32 + l31;
-        fw[buf][i] = *reinterpret_cast<const h8*>(Ws + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        for (int u = 0; u < KT; ++u) fetch_tile((stage ^ 1) * KT + u);
       }
     };
-    auto mma = [&](int buf) {
+    if (it * KT < n_mine)
+      compute_tile(stage * KT, refill);
+    else
+      refill();
 #pragma unroll
-      for (int i = 0; i < NF32; ++i)
+    for (int u = 1; u < KT; ++u)
+      if (it * KT + u < n_mine) compute_tile(stage * KT + u, no_mid);
+  }
+
+  // ---- k-groups: fixed-order sum of the groups' accumulators (and LayerNorm row sums) through LDS ------------------------------
+  if constexpr (KG > 1) {
+    __syncthreads();   // every group is done reading its stages
+    f4* const red = reinterpret_cast<f4*>(smem);
+    float* const red_ln = reinterpret_cast<float*>(smem + (KG - 1) * NF * MF * 4096);
+    if (kg > 0) {
 #pragma unroll
-        for (int j = 0; j < MF32; ++j)
-          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[buf][i], fa[buf][j], acc32[i][j], 0, 0, 0);
-    };
-    if (kt_begin < kt_end) {
-      fetch_tile(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt_begin + 1 < kt_end) fetch_tile(1);
-      rd(0, 0, 0);
-    }
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int stage = (kt - kt_begin) & 1;
+      for (int i = 0; i < NF; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int buf = ks & 1;
-        if (ks < 3) {
-          rd(stage, ks + 1, buf ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (kt + 1 < kt_end) {
-          // every wave holds its last fragments of `stage` in registers and the next tile has landed -> the stage may be re-armed
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          __syncthreads();
-          rd(stage ^ 1, 0, buf ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kt + 2 < kt_end) fetch_tile(stage);   // its address VALU / DMA issue interleaves with the MFMAs below
+        for (int j = 0; j < MF; ++j) red[((kg - 1) * NF * MF + i * MF + j) * 256 + tid] = acc[i][j];
+      if constexpr (LN) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          red_ln[((kg - 1) * MF * 2 + 2 * j) * 256 + tid] = ln_sum[j];
+          red_ln[((kg - 1) * MF * 2 + 2 * j + 1) * 256 + tid] = ln_sq[j];
         }
-        mma(buf);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
-  } else if constexpr (GLDS && STAGES > 2) {
-    constexpr int LPT = AJ + WJ;  // LDS-DMA instructions per thread per k-tile
+    __syncthreads();
+    if (kg == 0) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) fetch_tile(s, kt_begin + s < kt_end);
-    int stage = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");  // tile kt has landed (this wave's part)
-      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the stage refilled next
-      const int refill = stage == 0 ? STAGES - 1 : stage - 1;
-      compute_tile(stage, [&] { fetch_tile(refill, kt + STAGES - 1 < kt_end); });
-      stage = stage == STAGES - 1 ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the zero-page tail fetches before LDS is released
-  } else {
-    if constexpr (GLDS) {
-      if (kt_begin < kt_end) {
+      for (int q = 1; q < KG; ++q) {
 #pragma unroll
-        for (int u = 0; u < KT; ++u) fetch_tile(u, kt_begin + u < kt_end);
-      }
-    } else {
-      if (kt_begin < kt_end) {
-        fetch_tile(0);
-        store_tile(0);
-      }
-      __syncthreads();
-    }
-    for (int kt = kt_begin; kt < kt_end; kt += KT) {
-      const int stage = ((kt - kt_begin) / KT) & 1;
-      const bool more = kt + KT < kt_end;
-      if constexpr (GLDS) {
-        // explicit drain of this wave's LDS-DMA: the compiler's own wait before a barrier is not reliable for
-        // buffer_load..lds (see attention.hip), and a tile read before it has landed is a silent, rare corruption
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tiles kt.. have landed for every wave; every wave is done with stage^1
-#ifdef MD_IGEMM_DEBUG
-        const bool issue = more && !(g.dbg & 4);
-#else
-        const bool issue = more;
-#endif
-        // the refill of stage^1 is issued from INSIDE the first tile's compute, behind its first fragment reads
-        auto refill = [&] {
-          if (issue) {
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
-            for (int u = 0; u < KT; ++u) fetch_tile((stage ^ 1) * KT + u, kt + KT + u < kt_end);
+          for (int j = 0; j < MF; ++j) acc[i][j] += red[((q - 1) * NF * MF + i * MF + j) * 256 + tid];
+        if constexpr (LN) {
+#pragma unroll
+          for (int j = 0; j < MF; ++j) {
+            ln_sum[j] += red_ln[((q - 1) * MF * 2 + 2 * j) * 256 + tid];
+            ln_sq[j] += red_ln[((q - 1) * MF * 2 + 2 * j + 1) * 256 + tid];
           }
-        };
-        compute_tile(stage * KT, refill);
-#pragma unroll
-        for (int u = 1; u < KT; ++u)
-          if (kt + u < kt_end) compute_tile(stage * KT + u, no_mid);
-      } else {
-        if (more) fetch_tile(stage ^ 1);
-        compute_tile(stage, no_mid);
-        if (more) store_tile(stage ^ 1);
-        __syncthreads();
+        }
       }
     }
   }
+  const bool epi = kg == 0;   // the epilogue belongs to group 0; the other groups only keep the (uniform) barriers below company
 
   // ---- epilogue ---------------------------------------------------------------------------------------
   const __attribute__((address_space(4))) IgemmArgs* gp = (const __attribute__((address_space(4))) IgemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(gp));   // opaque: the loads below cannot move above the k-loop
   MD_LATE_LOAD(*gp)
-  if constexpr (M32) {
-    // fragment (i, j): lane holds column m = j*32 + l31 and, in registers 4q .. 4q+3, rows n = i*32 + 8q + 4 lh + (0..3)
-    if constexpr (LN) {
+  float* const e_part = gp->part;
+  if (!epi && !e_part) return;
+  if constexpr (LN) {
+    // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
+    // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
+    if (epi) {
 #pragma unroll
-      for (int j = 0; j < MF32; ++j) {
+      for (int j = 0; j < MF; ++j) {
         float sm = ln_sum[j], sq = ln_sq[j];
-        sm += __shfl_xor(sm, 32, 64);   // the two lane halves hold the two k-halves of every 16-deep step
+        sm += __shfl_xor(sm, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
         sq += __shfl_xor(sq, 32, 64);
         const float mu = sm * g.ln_inv_k;
         const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_k - mu * mu, 0.f) + g.ln_eps);
 #pragma unroll
-        for (int i = 0; i < NF32; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = min(n0 + wn * WTN + i * 32 + 8 * q + 4 * lh, g.N - 4);
-            const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc32[i][j][4 * q + e] = rstd * (acc32[i][j][4 * q + e] - mu * s1[e]) + s0[e];
-          }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < MF32; ++j) {
-      const int m = m0 + wm * WTM + j * 32 + l31;
-      if (m >= Mlim) continue;
-      const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
-#pragma unroll
-      for (int i = 0; i < NF32; ++i) {
-        if (g.act == MD_ACT_GEGLU && g.splitk <= 1) {
-          // packed rows [a0..15 | gate0..15] per 32: registers q = 0, 1 hold a, q = 2, 3 the gates of the same output columns
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int np = n0 + wn * WTN + i * 32 + 8 * q + 4 * lh;
-            if (np + 16 >= g.N) continue;
-            f4 av = {acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
-            f4 gv = {acc32[i][j][4 * q + 8], acc32[i][j][4 * q + 9], acc32[i][j][4 * q + 10], acc32[i][j][4 * q + 11]};
-            if (gbias) {
-              av += *reinterpret_cast<const f4*>(gbias + np);
-              gv += *reinterpret_cast<const f4*>(gbias + np + 16);
-            }
-            h4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
-            const int oc = (n0 + wn * WTN + i * 32) / 2 + 8 * q + 4 * lh;
-            *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + oc) = o;
-          }
-          continue;
+        for (int i = 0; i < NF; ++i) {
+          const int n = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4);
+          const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
+          acc[i][j] = rstd * (acc[i][j] - mu * s1) + s0;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * lh;
-          if (n >= g.N) continue;
-          const f4 v = {acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
-          if (g.splitk > 1)
-            *reinterpret_cast<f4*>(g.ws + ((long long)kz * g.M + m) * g.N + n) = v;
-          else
-            epi_store4(g, MD_LATE_ARGS, m, b, n, v);
-        }
-      }
-    }
-    return;
-  }
-  if constexpr (LN) {
-    // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
-    // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
-#pragma unroll
-    for (int j = 0; j < MF; ++j) {
-      float sm = ln_sum[j], sq = ln_sq[j];
-      sm += __shfl_xor(sm, 16, 64);
-      sq += __shfl_xor(sq, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      const float mu = sm * g.ln_inv_k;
-      const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_k - mu * mu, 0.f) + g.ln_eps);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const int n = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4);
-        const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
-        acc[i][j] = rstd * (acc[i][j] - mu * s1) + s0;
       }
     }
   }
   if (g.splitk > 1) {
+    if (!epi) return;
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
       const int m = m0 + wm * WTM + j * 16 + lr;
@@ -852,6 +654,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     return;
   }
   if (g.act == MD_ACT_GEGLU) {
+    if (!epi) return;
     if constexpr (NF % 2 == 0) {
 #pragma unroll
       for (int j = 0; j < MF; ++j) {
@@ -891,65 +694,117 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
     const half_t* __restrict__ const rlp = e_res_lo;
     half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
     half_t* __restrict__ const olp = e_out_lo;
+    // GroupNorm partials of this wave's rows (all inside ONE 64-row granule: WTM <= 64, tiles start on multiples of 64)
+    f4 ps[NF], pq[NF];
 #pragma unroll
-    for (int j = 0; j < MF; ++j) {
-      const int m = m0 + wm * WTM + j * 16 + lr;
-      const int mc = min(m, Mlim - 1);
-      const int b = fast_div(mc, g.div_tok_mul, g.div_tok_sh);
-      f4 bv[NF];
-      h4 rv[NF], rl[NF];
+    for (int i = 0; i < NF; ++i) ps[i] = pq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    if (epi) {
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        bv[i] = f4{0.f, 0.f, 0.f, 0.f};
-        rv[i] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-        rl[i] = rv[i];
-      }
-      if (has_bias) {   // (bias_bs == 0: the same vector for every row -- served by L1)
+      for (int j = 0; j < MF; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + lr;
+        const int mc = min(m, Mlim - 1);
+        const int b = fast_div(mc, g.div_tok_mul, g.div_tok_sh);
+        f4 bv[NF];
+        h4 rv[NF], rl[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
-          bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
-      }
-      if (resp) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-          rv[i] = *reinterpret_cast<const h4*>(resp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
-        if (rlp) {
+        for (int i = 0; i < NF; ++i) {
+          bv[i] = f4{0.f, 0.f, 0.f, 0.f};
+          rv[i] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          rl[i] = rv[i];
+        }
+        if (has_bias) {   // (bias_bs == 0: the same vector for every row -- served by L1)
 #pragma unroll
           for (int i = 0; i < NF; ++i)
-            rl[i] = *reinterpret_cast<const h4*>(rlp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+            bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+        }
+        if (resp) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            rv[i] = *reinterpret_cast<const h4*>(resp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          if (rlp) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              rl[i] = *reinterpret_cast<const h4*>(rlp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (m >= Mlim) continue;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int n = n0 + wn * WTN + i * 16 + lg * 4;
+          if (n >= g.N) continue;
+          f4 v = acc[i][j];
+          v += bv[i];
+          if (n < e_col_scale_end) v *= e_col_scale;
+          if (g.act == MD_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];   // (zeros when there is no residual / no second term)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
+          if (olp) {
+            h4 l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
+            *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
+          }
+          if (e_part) {   // statistics of the value the GroupNorm will read: the rounded fp16 hi term
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f = (float)o[e];
+              ps[i][e] += f;
+              pq[i][e] += f * f;
+            }
+          }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (m >= Mlim) continue;
+    }
+    if (e_part) {
+      // lane -> 16-row sum (DPP, fixed order) -> LDS [wave row][column][sum | sumsq] -> per 64-row granule and column, fixed order
+      float* const pred = reinterpret_cast<float*>(smem);
+      __syncthreads();   // the k-loop's / the k-group reduction's LDS reads are over
+      if (epi) {
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const int n = n0 + wn * WTN + i * 16 + lg * 4;
-        if (n >= g.N) continue;
-        f4 v = acc[i][j];
-        v += bv[i];
-        if (n < e_col_scale_end) v *= e_col_scale;
-        if (g.act == MD_ACT_SILU) {
+        for (int i = 0; i < NF; ++i) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+          for (int e = 0; e < 4; ++e) {
+            ps[i][e] = row16_sum(ps[i][e]);
+            pq[i][e] = row16_sum(pq[i][e]);
+          }
+          if (lr == 0) {
+            const int col = wn * WTN + i * 16 + lg * 4;
+            *reinterpret_cast<f4*>(pred + (wm * BN + col) * 2) = f4{ps[i][0], pq[i][0], ps[i][1], pq[i][1]};
+            *reinterpret_cast<f4*>(pred + (wm * BN + col) * 2 + 4) = f4{ps[i][2], pq[i][2], ps[i][3], pq[i][3]};
+          }
         }
+      }
+      __syncthreads();
+      if (epi && tid < BN && n0 + tid < g.N) {
+        constexpr int WPG = 64 / WTM > WAVES_M ? WAVES_M : 64 / WTM;   // wave rows per granule
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];   // (zeros when there is no residual / no second term)
+        for (int gi = 0; gi < (BM + 63) / 64; ++gi) {
+          if (m0 + gi * 64 >= Mlim) break;
+          float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
-        h4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
-        if (olp) {
-          h4 l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
-          *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
+          for (int w2 = 0; w2 < WPG; ++w2) {
+            s += pred[((gi * WPG + w2) * BN + tid) * 2];
+            q += pred[((gi * WPG + w2) * BN + tid) * 2 + 1];
+          }
+          float* dst = e_part + ((long long)(m0 / 64 + gi) * 2) * g.N + n0 + tid;
+          dst[0] = s;
+          dst[g.N] = q;
         }
       }
     }
     return;
   }
+  if (!epi) return;
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int m = m0 + wm * WTM + j * 16 + lr;
@@ -1002,21 +857,20 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
   epi_finish(g, MD_LATE_ARGS, m, m / g.tokens, n, s, ebv, erv, erl);
 }
 
-// config = 4 * family + tile; tiles: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
-// families: 0 register-staged | 1 global_load_lds + zero page, 2 stages | 2 same, 4 stages |
-//           3 buffer_load_lds (hw OOB), 2 stages | 4 same, 3 stages | 5 same, deep pipeline (6 stages; 4 for 128x128)
-const float kTileEff[18] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f, 0.70f, 0.60f, 1.0f, 1.0f, 1.0f, 1.0f};
-const int kTileBM[18] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64, 64, 64, 128, 128, 256, 256};
-const int kTileBN[18] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160, 64, 80, 128, 160, 128, 160};
-constexpr int kNumFamilies = 6;
-constexpr int kNumCfgs = 4 * kNumFamilies;
-// configs 24..27: SD-shaped tiles of the buffer loader (2 stages) -- 128x80, 128x160, 64x160, 64x80.  Every channel count of
-// SD-1.5 is a multiple of 80 (320 = 4 x 80), so these cover N exactly where the 64 / 128-wide tiles waste up to 17 %, and e.g.
-// M = 8192, N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
-// configs 28..31: two k-tiles per stage (KT = 2) for 64x64, 64x80, 128x80, 64x160 -- half the HBM round trips in the k-loop
-// of the small cold-weight GEMMs of a 1-frame step; 32, 33: four k-tiles per stage for 64x64, 64x80 (128 / 147 KB of LDS).
-// configs 34..37: 32x32x16-fragment tiles -- 128x128 (2x2 waves), 128x160 (4x1), 256x128 (4x1), 256x160 (4x1)
-constexpr int kFirstSdCfg = 24, kNumAllCfgs = 38;
+// Tile configs (ids are stable: igemm_tuned.inc refers to them).
+//   4..7   LOADER 1 (global_load_lds + zero page; ragged channel counts): 128x128, 128x64, 64x128, 64x64
+//   12..15 LOADER 2 (buffer_load..lds, hardware out-of-range zeros):      128x128, 128x64, 64x128, 64x64
+//   24..27 SD-shaped tiles of the buffer loader -- 128x80, 128x160, 64x160, 64x80.  Every channel count of SD-1.5 is a multiple
+//          of 80 (320 = 4 x 80), so these cover N exactly where the 64 / 128-wide tiles waste up to 17 %, and e.g. M = 8192,
+//          N = 320 becomes exactly 256 workgroups of 128x80 (one per CU) moving 33 % fewer L2->LDS bytes than 64x64 tiles.
+//   28..31 two k-tiles per stage (KT = 2) for 64x64, 64x80, 128x80, 64x160 -- half the HBM round trips in the k-loop of the small
+//          cold-weight GEMMs of a 1-frame step; 32, 33: four k-tiles per stage for 64x64, 64x80 (128 / 147 KB of LDS).
+// Every buffer-loader config also exists with 2 (and, LDS / registers permitting, 4) k-groups per workgroup: max_kg().
+const float kTileEff[14] = {1.00f, 0.85f, 0.85f, 0.70f, 0.90f, 1.00f, 0.85f, 0.60f, 0.70f, 0.60f, 0.90f, 0.85f, 0.70f, 0.60f};
+const int kTileBM[14] = {128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 64, 64, 64};
+const int kTileBN[14] = {128, 64, 128, 64, 80, 160, 160, 80, 64, 80, 80, 160, 64, 80};
+constexpr int kFirstSdCfg = 24, kNumAllCfgs = 34;
+inline bool cfg_exists(int c) { return (c >= 4 && c < 8) || (c >= 12 && c < 16) || (c >= kFirstSdCfg && c < kNumAllCfgs); }
 struct TileCfg {
   int bm, bn;
   float eff;
@@ -1026,46 +880,55 @@ inline TileCfg cfg_of(int c) {
   return TileCfg{kTileBM[t], kTileBN[t], kTileEff[t]};
 }
 // tiles whose per-wave fragment count along N is odd cannot host the GEGLU pairing
-inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28 || c == 32 || c >= 34; }
-inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || (c >= kFirstSdCfg && c < 34); }
-// default loader family: MD_IGEMM_LOADER = 0..4
-int g_default_loader = [] {
-  const char* e = getenv("MD_IGEMM_LOADER");
-  return (e && e[0] >= '0' && e[0] < '0' + kNumFamilies) ? e[0] - '0' : 3;
-}();
+inline bool cfg_geglu_ok(int c) { return c < kFirstSdCfg || c == 28 || c == 32; }
+inline bool cfg_ln_ok(int c) { return (c >= 12 && c < 16) || (c >= kFirstSdCfg && c < kNumAllCfgs); }
+// k-groups per workgroup a config is instantiated with: 160 KB of LDS (KG x 2 stages x KT tiles) and, for KG = 4, 128 VGPRs
+inline int max_kg(int c) {
+  switch (c) {
+    case 15: case 27: return 4;
+    case 12: case 13: case 14: case 24: case 25: case 26: case 28: case 29: return 2;
+    default: return 1;
+  }
+}
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, int STAGES, bool LN = false, int KT = 1, bool M32 = false, bool KS1 = false>
+template <int BM, int BN, int WMv, int WNv, int LOADER, bool LN = false, int KT = 1, bool KS1 = false, int KG = 1>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
-  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)KG * 2 * KT * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "stages do not fit the 160 KB LDS");
   static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
   if (lds > 65536) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32, KS1>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS1, KG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, STAGES, LN, KT, M32, KS1>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS1, KG>), grid, dim3(256 * KG), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
 
-// the 2-stage buffer-loader tiles exist with and without the folded LayerNorm
-template <int BM, int BN, int WMv, int WNv, int KT = 1>
-int launch_buf2(const IgemmArgs& g, hipStream_t s) {
+// the buffer-loader tiles exist with and without the folded LayerNorm, with the generic and the 1x1 issue path
+template <int BM, int BN, int WMv, int WNv, int KT, int KG>
+int launch_buf_kg(const IgemmArgs& g, hipStream_t s) {
   // the folded LayerNorm exists for 1x1 / linear layers only (validate()): always the KS1 issue path; others: KS1 when it applies
-  if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, 2, true, KT, false, true>(g, s);
+  if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, true, KT, true, KG>(g, s);
   const bool ks1 = g.ksize == 1 && g.stride == 1 && !g.ups && g.c1 == 0;
-  return ks1 ? launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT, false, true>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, 2, false, KT>(g, s);
+  return ks1 ? launch_cfg<BM, BN, WMv, WNv, 2, false, KT, true, KG>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, false, KT, false, KG>(g, s);
 }
-// 32x32x16-fragment tiles (2-stage buffer loader)
-template <int BM, int BN, int WMv, int WNv>
-int launch_m32(const IgemmArgs& g, hipStream_t s) {
-  if (g.ln_s1) return MD_ERR_UNSUPPORTED;   // the folded-LayerNorm GEMMs are small-M: they stay on the 16x16 tiles
-  return launch_cfg<BM, BN, WMv, WNv, 2, 2, false, 1, true>(g, s);
+template <int BM, int BN, int WMv, int WNv, int KT = 1, int MAXKG = 1>
+int launch_buf2(const IgemmArgs& g, hipStream_t s, int kg) {
+  if constexpr (MAXKG >= 4) {
+    if (kg == 4) return launch_buf_kg<BM, BN, WMv, WNv, KT, 4>(g, s);
+  }
+  if constexpr (MAXKG >= 2) {
+    if (kg == 2) return launch_buf_kg<BM, BN, WMv, WNv, KT, 2>(g, s);
+  }
+  if (kg != 1) return MD_ERR_UNSUPPORTED;
+  return launch_buf_kg<BM, BN, WMv, WNv, KT, 1>(g, s);
 }
 
 void fast_div_magic(unsigned d, unsigned* mul, unsigned* sh) {
@@ -1096,6 +959,10 @@ int validate(const md_igemm_params* p) {
   if (p->n_tr_begin < 0 || p->n_tr_begin > p->n || (p->n_tr_begin < p->n && (p->n_tr_begin & 15))) return MD_ERR_BAD_ARG;
   if (p->n_tr_begin < p->n && (!p->out_t || p->ld_t <= 0)) return MD_ERR_BAD_ARG;
   if (p->bias_batch_stride & 3) return MD_ERR_BAD_ARG;
+  if (p->gn_part) {   // GroupNorm partials: the common fp16 epilogue, whole 64-row granules per sample
+    if (p->out_f32 || p->n_tr_begin != p->n || p->k8 || p->act == MD_ACT_GEGLU || ((p->hout * p->wout) & 63)) return MD_ERR_UNSUPPORTED;
+  }
+  if (p->force_kg != 0 && p->force_kg != 1 && p->force_kg != 2 && p->force_kg != 4) return MD_ERR_BAD_ARG;
   if (p->w2 && p->batch2 > 0) {
     if (p->batch2 >= p->batch || p->bias_batch_stride) return MD_ERR_UNSUPPORTED;
     if ((p->bias != nullptr) != (p->bias2 != nullptr) || (p->ln_s1 != nullptr) != (p->ln2_s1 != nullptr) ||
@@ -1112,18 +979,19 @@ int validate(const md_igemm_params* p) {
 
 // Measured-best (config, split-K) per layer shape, generated on an MI355X by tools/tune_igemm.py
 struct TunedEntry {
-  int m, n, k, ksize, stride, ups, cfg, split;
+  int m, n, k, ksize, stride, ups, cfg, split, kg;   // kg 0 (entries older than the k-groups): the rule in choose() decides
 };
 const TunedEntry kTuned[] = {
 #include "igemm_tuned.inc"
-    {0, 0, 0, 0, 0, 0, 0, 0}};
+    {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 int g_use_tuned = [] {
   const char* e = getenv("MD_IGEMM_TUNED");
   return (e && e[0] == '0') ? 0 : 1;
 }();
 
 // Pick tile config + split-K: tuned table first, otherwise a crude time model (overridable: force_cfg / force_splitk).
-void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_bytes, int* cfg_out, int* split_out) {
+void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_bytes, int* cfg_out, int* split_out, int* kg_out) {
+  *kg_out = 0;
   const int nk = (K + 63) / 64;
   // two parameter sets: a batch of 3F samples (2F UNet + F ControlNet) is not in the table -- the entry of the 2F-sample layer
   // (same N, K, tile economics; 1.5x the workgroups) is the second choice before the model below
@@ -1137,23 +1005,24 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
         const bool ok_buf = t->cfg < 12 || (((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0));
         const bool ok_act = cfg_geglu_ok(t->cfg) || p->act != MD_ACT_GEGLU;
         const bool ok_ln = !p->ln_s1 || (t->split == 1 && cfg_ln_ok(t->cfg));
-        if (ok_split && ok_buf && ok_act && ok_ln) {
+        if (ok_split && ok_buf && ok_act && ok_ln && cfg_exists(t->cfg)) {
           *cfg_out = t->cfg;
           *split_out = t->split;
+          *kg_out = t->kg;
           return;
         }
       }
     }
   }
   double best = 1e30;
-  int bc = 4 * g_default_loader + 3, bs = 1;
-  if (g_default_loader >= 3 && !(((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0))) bc = 7;
   // the buffer-descriptor loader needs tile-uniform (tap, source): 64-channel k-tiles must not straddle either
   const bool buf_ok = ((p->c0 + p->c1) % 64 == 0) && (p->c0 % 64 == 0);
-  const int fam = (g_default_loader >= 3 && !buf_ok) ? 1 : g_default_loader;
+  const int fam = buf_ok ? 3 : 1;
+  int bc = 4 * fam + 3, bs = 1;
   for (int c = 0; c < kNumAllCfgs; ++c) {
+    if (!cfg_exists(c)) continue;
     if (p->force_cfg >= 0 && c != p->force_cfg) continue;
-    if (p->force_cfg < 0 && (c >= kNumCfgs || c / 4 != fam)) continue;
+    if (p->force_cfg < 0 && (c >= 16 || c / 4 != fam)) continue;
     const long long tm = (M + cfg_of(c).bm - 1) / cfg_of(c).bm, tn = (N + cfg_of(c).bn - 1) / cfg_of(c).bn;
     const long long blocks = tm * tn;
     const double rate_cu = 2.5e15 / 256.0 * 0.35 * cfg_of(c).eff;  // flop/s per CU we expect from this tile
@@ -1178,6 +1047,21 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
   if (p->force_cfg >= 0 && best > 1e29) bc = p->force_cfg;
   *cfg_out = bc;
   *split_out = bs;
+}
+
+// k-groups for a (config, split) that carries no measured choice: turn global split-K into in-workgroup k-groups where the
+// config has them (no slabs, no reduce launch), and give grids that leave CUs without a second workgroup more waves per tile.
+int default_kg(int cfg, int* split, long long tiles, int nk, bool allow) {
+  const int mk = allow ? max_kg(cfg) : 1;
+  if (mk == 1) return 1;
+  if (*split > 1) {
+    int kg = (mk >= 4 && *split % 4 == 0) ? 4 : ((*split % 2 == 0) ? 2 : 1);
+    *split /= kg;
+    return kg;
+  }
+  if (tiles <= 256 && nk >= 16 && mk >= 4) return 4;
+  if (tiles <= 256 && nk >= 8) return 2;
+  return 1;
 }
 
 }  // namespace
@@ -1249,22 +1133,30 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.ln2_s0 = dual ? p->ln2_s0 : g.ln_s0;
   g.m_split = dual ? p->batch2 * g.tokens : 0x7fffffff;
   g.ln_inv_k = 1.0f / (float)g.K;
-  static const int early_w = [] {
-    const char* e = getenv("MD_IGEMM_EARLY_W");
-    return e ? atoi(e) : 1;
-  }();
-  g.early_w = early_w;
-  static const int dbg = [] {
-    const char* e = getenv("MD_IGEMM_DEBUG");
-    return e ? atoi(e) : 0;
-  }();
-  g.dbg = dbg;
-  int cfg, split;
-  choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split);
+  g.part = (float*)p->gn_part;
+  int cfg, split, kg;
+  choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split, &kg);
+  if (!cfg_exists(cfg)) return MD_ERR_BAD_ARG;
   if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
+  if (g.part && split > 1) {   // the partials come from the in-kernel epilogue
+    if (p->force_splitk > 1) return MD_ERR_UNSUPPORTED;
+    split = 1;
+    kg = 0;
+  }
+  if (p->force_kg > 0) {
+    kg = p->force_kg;
+  } else if (kg <= 0) {
+    static const int kg_rule = [] {   // MD_IGEMM_KG=0: no k-groups unless forced / tuned (A/B, tools/tune_igemm.py)
+      const char* e = getenv("MD_IGEMM_KG");
+      return e ? atoi(e) : 1;
+    }();
+    const long long tl = ((M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm) * ((g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn) * split;
+    kg = default_kg(cfg, &split, tl, g.nk, kg_rule != 0 && p->force_splitk <= 0);
+  }
+  if (kg > max_kg(cfg)) return MD_ERR_UNSUPPORTED;
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
-  if (cfg >= kNumAllCfgs || (p->act == MD_ACT_GEGLU && !cfg_geglu_ok(cfg))) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
+  if (p->act == MD_ACT_GEGLU && !cfg_geglu_ok(cfg)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
   if (p->ln_s1 && (split > 1 || !cfg_ln_ok(cfg))) return MD_ERR_UNSUPPORTED;
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
@@ -1287,50 +1179,30 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   char tag[128];
-  snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d B=%d h=%d w=%d c0=%d c1=%d act=%d", M, g.N, g.K,
-           g.ksize, g.stride, g.ups, cfg, split, g.batch, g.hin, g.win, g.c0, g.c1, g.act);
+  snprintf(tag, sizeof(tag), "M=%lld N=%d K=%d ks=%d st=%d up=%d cfg=%d split=%d kg=%d B=%d h=%d w=%d c0=%d c1=%d act=%d", M, g.N, g.K,
+           g.ksize, g.stride, g.ups, cfg, split, kg, g.batch, g.hin, g.win, g.c0, g.c1, g.act);
   md::ProfScope prof(MD_FAM_IGEMM, s, 2.0 * (double)M * g.N * g.K,
                      (double)M * g.cin * 2.0 + (double)g.N * g.K * 2.0 + (double)M * g.N * 2.0, tag);
   int rc;
   switch (cfg) {
-    case 24: rc = launch_buf2<128, 80, 4, 1>(g, s); break;
-    case 25: rc = launch_buf2<128, 160, 2, 2>(g, s); break;
-    case 26: rc = launch_buf2<64, 160, 2, 2>(g, s); break;
-    case 27: rc = launch_buf2<64, 80, 4, 1>(g, s); break;
-    case 28: rc = launch_buf2<64, 64, 2, 2, 2>(g, s); break;
-    case 29: rc = launch_buf2<64, 80, 4, 1, 2>(g, s); break;
-    case 30: rc = launch_buf2<128, 80, 4, 1, 2>(g, s); break;
-    case 31: rc = launch_buf2<64, 160, 2, 2, 2>(g, s); break;
-    case 32: rc = launch_buf2<64, 64, 2, 2, 4>(g, s); break;
-    case 33: rc = launch_buf2<64, 80, 4, 1, 4>(g, s); break;
-    case 34: rc = launch_m32<128, 128, 2, 2>(g, s); break;
-    case 35: rc = launch_m32<128, 160, 4, 1>(g, s); break;
-    case 36: rc = launch_m32<256, 128, 4, 1>(g, s); break;
-    case 37: rc = launch_m32<256, 160, 4, 1>(g, s); break;
-    case 0: rc = launch_cfg<128, 128, 2, 2, 0, 2>(g, s); break;
-    case 1: rc = launch_cfg<128, 64, 2, 2, 0, 2>(g, s); break;
-    case 2: rc = launch_cfg<64, 128, 2, 2, 0, 2>(g, s); break;
-    case 3: rc = launch_cfg<64, 64, 2, 2, 0, 2>(g, s); break;
-    case 4: rc = launch_cfg<128, 128, 2, 2, 1, 2>(g, s); break;
-    case 5: rc = launch_cfg<128, 64, 2, 2, 1, 2>(g, s); break;
-    case 6: rc = launch_cfg<64, 128, 2, 2, 1, 2>(g, s); break;
-    case 7: rc = launch_cfg<64, 64, 2, 2, 1, 2>(g, s); break;
-    case 8: rc = launch_cfg<128, 128, 2, 2, 1, 4>(g, s); break;
-    case 9: rc = launch_cfg<128, 64, 2, 2, 1, 4>(g, s); break;
-    case 10: rc = launch_cfg<64, 128, 2, 2, 1, 4>(g, s); break;
-    case 11: rc = launch_cfg<64, 64, 2, 2, 1, 4>(g, s); break;
-    case 12: rc = launch_buf2<128, 128, 2, 2>(g, s); break;
-    case 13: rc = launch_buf2<128, 64, 2, 2>(g, s); break;
-    case 14: rc = launch_buf2<64, 128, 2, 2>(g, s); break;
-    case 15: rc = launch_buf2<64, 64, 2, 2>(g, s); break;
-    case 16: rc = launch_cfg<128, 128, 2, 2, 2, 3>(g, s); break;
-    case 17: rc = launch_cfg<128, 64, 2, 2, 2, 3>(g, s); break;
-    case 18: rc = launch_cfg<64, 128, 2, 2, 2, 3>(g, s); break;
-    case 19: rc = launch_cfg<64, 64, 2, 2, 2, 3>(g, s); break;
-    case 20: rc = launch_cfg<128, 128, 2, 2, 2, 4>(g, s); break;
-    case 21: rc = launch_cfg<128, 64, 2, 2, 2, 6>(g, s); break;
-    case 22: rc = launch_cfg<64, 128, 2, 2, 2, 6>(g, s); break;
-    case 23: rc = launch_cfg<64, 64, 2, 2, 2, 6>(g, s); break;
+    case 24: rc = launch_buf2<128, 80, 4, 1, 1, 2>(g, s, kg); break;
+    case 25: rc = launch_buf2<128, 160, 2, 2, 1, 2>(g, s, kg); break;
+    case 26: rc = launch_buf2<64, 160, 2, 2, 1, 2>(g, s, kg); break;
+    case 27: rc = launch_buf2<64, 80, 4, 1, 1, 4>(g, s, kg); break;
+    case 28: rc = launch_buf2<64, 64, 2, 2, 2, 2>(g, s, kg); break;
+    case 29: rc = launch_buf2<64, 80, 4, 1, 2, 2>(g, s, kg); break;
+    case 30: rc = launch_buf2<128, 80, 4, 1, 2>(g, s, kg); break;
+    case 31: rc = launch_buf2<64, 160, 2, 2, 2>(g, s, kg); break;
+    case 32: rc = launch_buf2<64, 64, 2, 2, 4>(g, s, kg); break;
+    case 33: rc = launch_buf2<64, 80, 4, 1, 4>(g, s, kg); break;
+    case 4: rc = launch_cfg<128, 128, 2, 2, 1>(g, s); break;
+    case 5: rc = launch_cfg<128, 64, 2, 2, 1>(g, s); break;
+    case 6: rc = launch_cfg<64, 128, 2, 2, 1>(g, s); break;
+    case 7: rc = launch_cfg<64, 64, 2, 2, 1>(g, s); break;
+    case 12: rc = launch_buf2<128, 128, 2, 2, 1, 2>(g, s, kg); break;
+    case 13: rc = launch_buf2<128, 64, 2, 2, 1, 2>(g, s, kg); break;
+    case 14: rc = launch_buf2<64, 128, 2, 2, 1, 2>(g, s, kg); break;
+    case 15: rc = launch_buf2<64, 64, 2, 2, 1, 4>(g, s, kg); break;
     default: return MD_ERR_BAD_ARG;
   }
   if (rc != MD_OK) return rc;

@@ -289,6 +289,123 @@ __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int
   }
 }
 
+// GroupNorm from PRODUCER partials (round 3; the ResBlock's "conv + GroupNorm + SiLU" fusion): the md_igemm that wrote x also
+// wrote, per 64-row granule and channel, the sum and the sum of squares of the fp16 values it stored (md_igemm_params.gn_part), so
+// the statistics pass over x disappears: a block = (row chunk, gper whole groups, sample) folds the partials of its groups
+// (hw / 64 granules x gper * cpg channels, fixed order -> deterministic) while its rows are already in flight, then normalises.
+// Two-source concat: channel ca < c0 reads part0 / x0, the rest part1 / x1 (a group may straddle the two).
+constexpr int GN_PART_MAXV = 8;
+__global__ __launch_bounds__(GN_SMALL_THREADS) void gn_part_apply(const GnArgs g, const float* __restrict__ part0,
+                                                                   const float* __restrict__ part1, int gper, int cw8, int rows_per_block) {
+  __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
+  __shared__ float stat[2 * GN_GPER_MAX];  // mean[gper], rstd[gper]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int v = tid % cw8, pl = tid / cw8, ps = GN_SMALL_THREADS / cw8;  // fixed vector column, pixel lane, pixel stride
+  const bool active = pl < ps;
+  const int cbase = blockIdx.y * gper * g.cpg;
+  const int c = cbase + v * 8;
+  const bool first = c < g.c0;
+  const half_t* src = first ? g.x0 + c : g.x1 + (c - g.c0);
+  const long long cs = first ? g.c0 : g.c1;
+  const long long pix0 = (long long)b * g.hw;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(g.hw, r0 + rows_per_block);
+  // (1) this thread's rows: all loads in flight before anything is consumed
+  h8 x[GN_PART_MAXV];
+#pragma unroll
+  for (int i = 0; i < GN_PART_MAXV; ++i) {
+    const int p = r0 + pl + i * ps;
+    if (active && p < r1) x[i] = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+  }
+  // (2) partials of this block's channels: thread = (channel cl, granule lane); granules of sample b are rows b*P .. of the table
+  const int cw = gper * g.cpg, P = g.hw >> 6, pls = GN_SMALL_THREADS / cw;
+  const int cl = tid % cw, pg = tid / cw;
+  float s = 0.f, q = 0.f;
+  if (pg < pls) {
+    const int ca = cbase + cl;
+    const bool f0 = ca < g.c0;
+    const float* pt = f0 ? part0 + ca : part1 + (ca - g.c0);
+    const long long pc = f0 ? g.c0 : g.c1;
+    for (int gr = pg; gr < P; gr += pls) {
+      const float* row = pt + ((long long)b * P + gr) * 2 * pc;
+      s += row[0];
+      q += row[pc];
+    }
+  }
+  const int lgk = cl / g.cpg;   // local group of this thread's partial channel
+  for (int k = 0; k < gper; ++k) {
+    float a = (pg < pls && lgk == k) ? s : 0.f;
+    float bq = (pg < pls && lgk == k) ? q : 0.f;
+    a = md::wave_sum(a);
+    bq = md::wave_sum(bq);
+    if (lane == 0) {
+      red[wave][2 * k] = a;
+      red[wave][2 * k + 1] = bq;
+    }
+  }
+  __syncthreads();
+  if (tid < gper) {
+    float sm = 0.f, sq = 0.f;
+    for (int w = 0; w < GN_SMALL_THREADS / 64; ++w) {
+      sm += red[w][2 * tid];
+      sq += red[w][2 * tid + 1];
+    }
+    const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
+    const float mu = sm * inv_n;
+    stat[tid] = mu;
+    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(sq * inv_n - mu * mu, 0.f) + g.eps);
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+  const float* gamma = b >= g.batch2 ? g.gamma2 : g.gamma;
+  const float* beta = b >= g.batch2 ? g.beta2 : g.beta;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int lge = (v * 8 + e) / g.cpg;
+    sc[e] = stat[GN_GPER_MAX + lge] * gamma[c + e];
+    sh[e] = beta[c + e] - stat[lge] * sc[e];
+  }
+  half_t* dst = g.out + c;
+#pragma unroll
+  for (int i = 0; i < GN_PART_MAXV; ++i) {
+    const int p = r0 + pl + i * ps;
+    if (p < r1) {
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = (float)x[i][e] * sc[e] + sh[e];
+        if (g.silu) y = md::silu_f(y);
+        o[e] = (half_t)y;
+      }
+      *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
+    }
+  }
+}
+
+// whole groups per block such that the block's channel slice is a multiple of 8 channels (16-byte vectors)
+inline bool gn_group_block(int cpg, int groups, int* gper, int* cw8) {
+  int gp = 1;
+  while (gp <= GN_GPER_MAX && ((gp * cpg) & 7)) gp <<= 1;
+  if (gp > GN_GPER_MAX || groups % gp) return false;
+  *gper = gp;
+  *cw8 = gp * cpg / 8;
+  return *cw8 >= 1 && *cw8 <= GN_SMALL_THREADS;
+}
+const long long g_gn_small_bytes = [] {
+  const char* e = getenv("MD_GN_SMALL_BYTES");
+  return e ? atoll(e) : 96LL << 10;
+}();
+// small slices: one launch, a block owns whole groups of one sample and all its pixels (gn_small)
+inline bool gn_small_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
+  return gn_group_block(cpg, groups, gper, cw8) && (long long)hw * *gper * cpg * 2 <= g_gn_small_bytes &&
+         hw <= GN_SMALL_MAXV * (GN_SMALL_THREADS / *cw8);
+}
+// producer partials usable: 64-row granules per sample, group blocks of whole 16-byte vectors
+inline bool gn_part_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
+  return (hw & 63) == 0 && gn_group_block(cpg, groups, gper, cw8) && *gper * cpg <= GN_SMALL_THREADS;
+}
+
 // stats grid geometry shared by the launcher and the workspace query
 inline void gn_geometry(int batch, int hw, int c, int* ty, int* pix_per_chunk, int* nchunks) {
   const int ch8 = c >> 3;
@@ -365,6 +482,14 @@ extern "C" int64_t md_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32
   return (int64_t)batch * groups * nchunks * 2 * sizeof(float);
 }
 
+extern "C" int md_groupnorm_wants_partials(int32_t batch, int32_t hw, int32_t c, int32_t groups) {
+  (void)batch;
+  if (groups <= 0 || c <= 0 || c % groups) return 0;
+  int gper = 1, cw8 = 1;
+  if (gn_small_ok(hw, c / groups, groups, &gper, &cw8)) return 0;
+  return gn_part_ok(hw, c / groups, groups, &gper, &cw8) ? 1 : 0;
+}
+
 extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   if (!p || !p->x0 || !p->gamma || !p->beta || !p->out || !p->ws) return MD_ERR_BAD_ARG;
   const int c = p->c0 + p->c1;
@@ -401,17 +526,17 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
   g.ws = (float*)p->ws;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_NORM, s, 0.0, (double)p->batch * p->hw * c * 2.0 * 3.0);
-  {  // small slices: one launch, a block owns whole groups of one sample (see gn_small)
-    static const long long small_bytes = [] {
-      const char* e = getenv("MD_GN_SMALL_BYTES");
-      return e ? atoll(e) : 96LL << 10;
-    }();
-    int gper = 1;
-    while (gper <= GN_GPER_MAX && ((gper * g.cpg) & 7)) gper <<= 1;
-    const int cw8 = gper * g.cpg / 8;
-    if (gper <= GN_GPER_MAX && p->groups % gper == 0 && (long long)p->hw * gper * g.cpg * 2 <= small_bytes &&
-        cw8 >= 1 && cw8 <= GN_SMALL_THREADS && p->hw <= GN_SMALL_MAXV * (GN_SMALL_THREADS / cw8)) {
+  {
+    int gper = 1, cw8 = 1;
+    if (gn_small_ok(p->hw, g.cpg, p->groups, &gper, &cw8)) {
       hipLaunchKernelGGL(gn_small, dim3(p->groups / gper, g.batch), dim3(GN_SMALL_THREADS), 0, s, g, gper, cw8);
+      MD_HIP_CHECK(hipGetLastError());
+      return MD_OK;
+    }
+    if (p->part0 && (p->c1 == 0 || p->part1) && gn_part_ok(p->hw, g.cpg, p->groups, &gper, &cw8)) {
+      const int rows_per_block = GN_PART_MAXV * (GN_SMALL_THREADS / cw8);
+      hipLaunchKernelGGL(gn_part_apply, dim3((p->hw + rows_per_block - 1) / rows_per_block, p->groups / gper, g.batch),
+                         dim3(GN_SMALL_THREADS), 0, s, g, p->part0, p->part1 ? p->part1 : p->part0, gper, cw8, rows_per_block);
       MD_HIP_CHECK(hipGetLastError());
       return MD_OK;
     }

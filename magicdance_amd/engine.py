@@ -79,6 +79,9 @@ _FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
 # reference's CPU path) carry the part their fp16 store dropped to the next link, so the chain's rounding does not accumulate
 # with depth (md_igemm res_lo / out_lo).  MD_RES_LO=0 restores the single-term stream (parity / cost A-B).
 _RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
+# GroupNorm statistics from the producing conv's epilogue (md_igemm gn_part -> md_groupnorm part0 / part1).  MD_GN_FUSE=0: every
+# GroupNorm computes its own statistics (A/B, and the parity reference of the fused form in tests/test_gpu_e2e.py).
+_GN_FUSE = os.environ.get("MD_GN_FUSE", "1") != "0"
 # fp8 attention path (BASELINE configs[4]): the self / bank attention's K and V^T are written as OCP e4m3 bytes by the projection
 # GEMMs and md_attention runs its contractions on the fp8 MFMA (q and P converted in registers).  Off by default (the fp16 path is
 # the parity path); bench.py --fp8-attention / MD_ATTN_FP8=1 switch it on BEFORE the engines are built.
@@ -156,11 +159,13 @@ def fold_layernorm(w, b, gamma, beta, device):
 
 class Act:
     """NHWC fp16 activation handle: tensor [B, H*W, C] + spatial dims.  ``lo`` (same shape, fp16, or None) is the second
-    term of a two-term residual-stream value: the chain value is t + lo, every GEMM / norm consumer reads t alone."""
-    __slots__ = ("t", "b", "h", "w", "c", "lo")
+    term of a two-term residual-stream value: the chain value is t + lo, every GEMM / norm consumer reads t alone.
+    ``part`` (fp32 [B*H*W / 64, 2, C] or None): the GroupNorm partial statistics the producing md_igemm wrote for ``t``
+    (sum | sum of squares per 64-row granule and channel); None once anything else has modified ``t``."""
+    __slots__ = ("t", "b", "h", "w", "c", "lo", "part")
 
-    def __init__(self, t, b, h, w, c, lo=None):
-        self.t, self.b, self.h, self.w, self.c, self.lo = t, b, h, w, c, lo
+    def __init__(self, t, b, h, w, c, lo=None, part=None):
+        self.t, self.b, self.h, self.w, self.c, self.lo, self.part = t, b, h, w, c, lo, part
 
     @property
     def hw(self):
@@ -168,12 +173,13 @@ class Act:
 
     def head(self, nb):
         """first nb samples (batch is the outermost dim, so this is a contiguous prefix)"""
-        return Act(self.t[:nb], nb, self.h, self.w, self.c, None if self.lo is None else self.lo[:nb])
-
+        return Act(self.t[:nb], nb, self.h, self.w, self.c, None if self.lo is None else self.lo[:nb],
+                   None if self.part is None else self.part[:nb * self.hw // 64])
 
     def tail(self, nb):
         """samples nb.. (the second network's samples of a merged batch)"""
-        return Act(self.t[nb:], self.b - nb, self.h, self.w, self.c, None if self.lo is None else self.lo[nb:])
+        return Act(self.t[nb:], self.b - nb, self.h, self.w, self.c, None if self.lo is None else self.lo[nb:],
+                   None if self.part is None else self.part[nb * self.hw // 64:])
 
 
 class Dual:
@@ -342,10 +348,23 @@ class NetEngine:
             buf[:16384].zero_()  # split-K arrival counters (md_igemm re-arms them after every use)
         return buf
 
+    _WANT = {}
+
+    @classmethod
+    def want_part(cls, b, hw, c):
+        """Should the conv that writes a [b, hw, c] tensor also write its GroupNorm partial statistics?  Yes where md_groupnorm
+        would otherwise run its own statistics pass over the tensor (large slices: the 64x64 level), see md_groupnorm_wants_partials."""
+        key = (hw, c)
+        if key not in cls._WANT:
+            cls._WANT[key] = _GN_FUSE and hw % 64 == 0 and c % 32 == 0 and ops.groupnorm_wants_partials(b, hw, c, 32)
+        return cls._WANT[key]
+
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
-             out_f32=False, out=None, ln=None, lo=False, col_scale=None):
+             out_f32=False, out=None, ln=None, lo=False, col_scale=None, stats=False):
         """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act.  ``lo``: the output is a link of
-        a residual chain -- also store what the fp16 rounding dropped (Act.lo), to be added back by the next link."""
+        a residual chain -- also store what the fp16 rounding dropped (Act.lo), to be added back by the next link.  ``stats``:
+        the output may feed a GroupNorm -- let the epilogue write its partial statistics (Act.part) where that saves the
+        GroupNorm's own pass; a tensor: the partials buffer to refresh (in-place add into part of an existing tensor)."""
         hin, win = x.h, x.w
         if ups:
             hout, wout = 2 * hin, 2 * win
@@ -361,13 +380,18 @@ class NetEngine:
             out_lo = lo
         else:
             out_lo = self.arena.alloc((x.b, hout * wout, nout), F16) if (lo and _RES_LO and not out_f32) else None
+        part = None
+        if isinstance(stats, torch.Tensor):
+            part = stats
+        elif stats and act != MD_ACT_GEGLU and not out_f32 and self.want_part(x.b, hout * wout, nout):
+            part = self.arena.alloc((x.b * hout * wout // 64, 2, nout), F32)
         ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
                   out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale,
-                  set2=set2)
+                  set2=set2, gn_part=part)
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
-        return Act(out, x.b, hout, wout, nout, out_lo)
+        return Act(out, x.b, hout, wout, nout, out_lo, part)
 
     def _sets(self, w, bias, ln):
         """(w, bias, ln, set2) of a GEMM whose parameters may be Dual pairs (merged two-network pass)"""
@@ -395,8 +419,12 @@ class NetEngine:
         set2 = None
         if isinstance(gb[0], Dual):
             set2, gb = (self._batch2, gb[0].b, gb[1].b), (gb[0].a, gb[1].a)
+        # statistics from the producers' epilogues where every source carries them (Act.part); otherwise md_groupnorm's own pass
+        parts = (x.part, None if x1 is None else x1.part)
+        if parts[0] is None or (x1 is not None and parts[1] is None):
+            parts = (None, None)
         ops.groupnorm(x.t, gb[0], gb[1], out, self._gn_ws(), batch=x.b, hw=x.hw, c0=x.c, x1=None if x1 is None else x1.t,
-                      c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu, set2=set2)
+                      c1=0 if x1 is None else x1.c, groups=32, eps=eps, silu=silu, set2=set2, part0=parts[0], part1=parts[1])
         _chk(out, f"groupnorm c={c} hw={x.hw} b={x.b}")
         return Act(out, x.b, x.h, x.w, c)
 
@@ -485,14 +513,15 @@ class NetEngine:
     def resblock(self, r, x, emb, x1=None):
         h = self.gn(x, r["gn1"], x1=x1, silu=True)
         # emb: one row per sample, or ONE row shared by the whole batch (all samples of a DDIM step share the timestep)
-        h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total if emb.shape[0] > 1 else 0)
+        h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total if emb.shape[0] > 1 else 0,
+                      stats=True)
         h = self.gn(h, r["gn2"], silu=True)
         if "skip_w" in r:
             skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"], lo=True)
         else:
             assert x1 is None
             skip = x
-        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True)
+        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True, stats=True)
 
     @staticmethod
     def qscale(dh):
@@ -599,7 +628,7 @@ class NetEngine:
                 ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
             t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
         t = Act(t.t, b, x.h, x.w, c)
-        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True)
+        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True, stats=True)
 
     def _project_bank(self, blk, bank, k_out, vt_out):
         bb, nb, c = bank.b, bank.hw, bank.c
@@ -633,11 +662,11 @@ class NetEngine:
                 if mode == "read":
                     bank_idx[0] += 1                                               # openaimodel.py:92-93
             elif kind == "down":
-                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"], lo=True)
+                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"], lo=True, stats=True)
             elif kind == "up":
-                h = self.conv(h, layer["w"], layer["c"], k=3, ups=1, bias=layer["b"])
+                h = self.conv(h, layer["w"], layer["c"], k=3, ups=1, bias=layer["b"], stats=True)
             elif kind == "stem":
-                h = self.conv(h, layer["w"], layer["cout"], k=3, bias=layer["b"], lo=True)
+                h = self.conv(h, layer["w"], layer["cout"], k=3, bias=layer["b"], lo=True, stats=True)
             else:
                 raise NotImplementedError(kind)
         assert x1 is None
@@ -697,7 +726,8 @@ class NetEngine:
             tgt = targets[i].head(nread)
             assert tgt.b == h.b and tgt.hw == h.hw and tgt.c == h.c
             torch.cuda.current_stream().wait_event(events[i])
-            self.conv(h, z["w"], h.c, k=1, bias=z["b"], res=tgt, out=tgt.t, lo=tgt.lo if tgt.lo is not None else False)
+            self.conv(h, z["w"], h.c, k=1, bias=z["b"], res=tgt, out=tgt.t, lo=tgt.lo if tgt.lo is not None else False,
+                      stats=tgt.part if tgt.part is not None else False)
 
         h = self.stem_input(x)
         for i, blk in enumerate(self.input_blocks):
@@ -705,6 +735,7 @@ class NetEngine:
             if i == 0:
                 n = h.b * h.hw * h.c
                 ops.add_f16(h.t, hint_feat.t, h.t, n, hint_feat.b * hint_feat.hw * hint_feat.c)  # h += guided_hint
+                h.part = None   # (the producer's partial statistics no longer describe h)
             zero_conv(i, h, self.zero_convs[i])
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
         zero_conv(len(self.input_blocks), h, self.mid_out)
@@ -749,12 +780,14 @@ class NetEngine:
             pr = pose.pop()                                                        # cldm.py:93-95
             hh = h.head(nread)
             ops.add_f16(hh.t, pr.t, hh.t, nread * h.hw * h.c, pr.b * pr.hw * pr.c)
+            h.part = None
         for blk in self.output_blocks:
             skip = hs.pop()
             if nread > 0 and pose is not None and not only_mid_control and use_bank:
                 pr = pose.pop()                                                    # cldm.py:102-104
                 sh = skip.head(nread)
                 ops.add_f16(sh.t, pr.t, sh.t, nread * skip.hw * skip.c, pr.b * pr.hw * pr.c)
+                skip.part = None
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank else None, banks, bank_idx, nread, x1=skip)
         hn = self.gn(h, self.head_gn, silu=True)
         if eps_out is None:
@@ -813,6 +846,7 @@ class NetEngine:
                 if i == 0:   # h += guided_hint on the ControlNet's samples
                     hp = h.tail(b2)
                     ops.add_f16(hp.t, hint_feat.t, hp.t, hp.b * hp.hw * hp.c, hint_feat.b * hint_feat.hw * hint_feat.c)
+                    h.part = None   # (input block 1's first GroupNorm computes its own statistics)
                 hs.append(h)
             h = self.run_block(mid, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
         finally:
@@ -820,7 +854,9 @@ class NetEngine:
 
         def zero_conv(src, z, tgt):
             hp, tg = src.tail(b2), tgt.head(nread)
-            self.conv(hp, z["w"], hp.c, k=1, bias=z["b"], res=tg, out=tg.t, lo=tg.lo if tg.lo is not None else False)
+            # (the epilogue also refreshes the partial statistics of the rows it rewrites: the decoder's concat GroupNorm reads them)
+            self.conv(hp, z["w"], hp.c, k=1, bias=z["b"], res=tg, out=tg.t, lo=tg.lo if tg.lo is not None else False,
+                      stats=tg.part if tg.part is not None else False)
 
         if nread > 0:
             zero_conv(h, pose_e.mid_out, h)                                        # cldm.py:93-95

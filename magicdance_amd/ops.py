@@ -24,8 +24,8 @@ RECORD = None
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None):
-    """See md_igemm.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0):
+    """See md_igemm.  ``gn_part``: fp32 [M / 64][2][n] receiving the GroupNorm partial statistics of the stored rows.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
     end, ld): those columns as e4m3 bytes; ``vt_fp8``: the transposed columns as e4m3 bytes.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
@@ -46,6 +46,7 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
     p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
     p.force_cfg, p.force_splitk, p.asym_pad = force_cfg, force_splitk, int(asym_pad)
+    p.gn_part, p.force_kg = _p(gn_part), int(force_kg)
     if ln is not None:
         p.ln_s1, p.ln_s0, p.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
     if set2 is not None:
@@ -55,7 +56,7 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
-        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8, set2)))
+        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8, set2, gn_part)))
     return out
 
 
@@ -85,8 +86,15 @@ def groupnorm_ws_bytes(batch, hw, groups=32):
     return int(_lib.load().md_groupnorm_workspace_bytes(batch, hw, groups))
 
 
-def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None):
-    """``set2`` = (batch2, gamma2, beta2): samples >= batch2 use the second affine pair."""
+def groupnorm_wants_partials(batch, hw, c, groups=32):
+    """True when md_groupnorm on this geometry would run a separate statistics pass (producer partials save it)."""
+    return bool(_lib.load().md_groupnorm_wants_partials(batch, hw, c, groups))
+
+
+def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None, part0=None,
+              part1=None):
+    """``set2`` = (batch2, gamma2, beta2): samples >= batch2 use the second affine pair.  ``part0`` / ``part1``: the partial
+    statistics md_igemm wrote for x0 / x1 (gn_part)."""
     lib = _lib.load()
     p = GroupNormParams()
     p.x0, p.x1, p.c0, p.c1 = _p(x0), _p(x1), c0, c1
@@ -95,6 +103,7 @@ def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=
     p.ws, p.ws_bytes = _p(ws), ws.numel() * ws.element_size()
     if set2 is not None:
         p.batch2, p.gamma2, p.beta2 = int(set2[0]), _p(set2[1]), _p(set2[2])
+    p.part0, p.part1 = _p(part0), _p(part1)
     _lib.check(lib.md_groupnorm(C.byref(p), stream_ptr()), "md_groupnorm")
     return out
 

@@ -92,13 +92,24 @@ TRAJ_CASES = {
     "c0_b1_s20": (64, 1, 20, 951),    # configs[0]: single frame, 20-step DDIM
     "c1_b1_s50": (64, 1, 50, 981),    # configs[1]: single frame, 50-step DDIM (the headline)
     "c2_b8_s2": (64, 8, 2, 981),      # configs[2] geometry: 8 pose frames as one batch (reference recipe train_tiktok.py:408-444)
+    # round 3.  configs[2] at the full 50 steps without a 2-hour 8-frame oracle run: the reference is per-sample independent
+    # (SURVEY 8c), so frame k of the 8-frame pose sequence sampled ALONE for 50 steps is what frame k of the batched run must equal.
+    # (side, frames, steps, probe t, pose frame of synth_inputs(frames=8), x_T scale)
+    "c2f3_b1_s50": (64, 1, 50, 981, 3, 1.0),
+    "c2f6_b1_s50": (64, 1, 50, 981, 6, 1.0),
+    # configs[4] geometry (768x768 = latent 96): eps pair + a 2-step trajectory
+    "c4_b1_s2": (96, 1, 2, 981, None, 1.0),
+    # realistic latent scale: the seeded weights predict an eps of std 0.29 that does not track the noise, so pred_x0 = x_t / sqrt(a_t)
+    # amplifies a unit-variance x_T to max|z| = 78 over 50 steps; with x_T / 16 the trajectory stays at the scale of a real SD-1.5
+    # latent (max|z| ~ 5) while the network's eps keeps its magnitude -- the case the ABSOLUTE parity tolerance is quoted on
+    "c1r_b1_s50": (64, 1, 50, 981, None, 1.0 / 16),
 }
 
 
 def run_traj_case(name):
     """Full-size parity fixtures: eps_c / eps_u of one apply_model pair and the WHOLE x_t trajectory of sample_log
     (log_every_t=1 -> intermediates['x_inter'] holds x_T and every x_{t-1}); bank / pose tensors as head slices + statistics."""
-    side, frames, steps, t_probe = TRAJ_CASES[name]
+    side, frames, steps, t_probe, pose_frame, xt_scale = (tuple(TRAJ_CASES[name]) + (None, 1.0))[:6]
     torch.manual_seed(0)
     t0 = time.time()
     m = ref_shim.build_reference_model({}, image_size=side)
@@ -108,12 +119,16 @@ def run_traj_case(name):
         sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
     m.load_state_dict(sd, strict=False)
     del sd
-    inp = synthetic.synth_inputs((side, side), frames=frames, seed=0)
+    inp = synthetic.synth_inputs((side, side), frames=frames if pose_frame is None else 8, seed=0)
+    if pose_frame is not None:   # ONE frame of the 8-frame pose sequence, sampled alone
+        inp["pose"] = inp["pose"][pose_frame:pose_frame + 1].contiguous()
+    inp["x_T"] = inp["x_T"] * xt_scale
     rep = lambda x: x.repeat(frames, 1, 1, 1) if x.dim() == 4 else x.repeat(frames, 1, 1)
     ref, ctx, x_T, pose = rep(inp["ref"]), rep(inp["ctx"]), rep(inp["x_T"]), inp["pose"]
     c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
     uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
     out = dict(geo_model_channels=320, geo_num_heads=8, side=side, frames=frames, t_probe=t_probe, steps=steps, seed=0,
+               pose_frame=-1 if pose_frame is None else pose_frame, xt_scale=xt_scale,
                x_T=inp["x_T"].numpy(), ref=inp["ref"].numpy(), ctx_sum=summarize(ctx), pose_sum=summarize(pose))
     t = torch.full((frames,), t_probe, dtype=torch.long)
     with torch.no_grad():

@@ -25,7 +25,7 @@ def _off(t, elems):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None):
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0):
     if set2 is not None:   # two parameter sets: samples >= batch2 use (w2, bias2, ln2) -- two plain calls on the two sample ranges
         b2, w2, bias2, ln2 = set2
         assert 0 < b2 < batch and bias_batch_stride == 0
@@ -35,12 +35,14 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
         kw = dict(hin=hin, win=win, hout=hout, wout=wout, c0=c0, ksize=ksize, stride=stride, ups=ups, c1=c1, ld_res=ld_res, act=act,
                   ld_out=ld_out, out_f32=out_f32, n_tr_begin=n_tr_begin, ld_t=ld_t, ws=ws, asym_pad=asym_pad, col_scale=col_scale,
                   vt_fp8=vt_fp8)
-        igemm(a0, w, n, batch=b2, a1=a1, bias=bias, res=res, out=out, out_t=out_t, ln=ln, res_lo=res_lo, out_lo=out_lo, k8=k8, **kw)
+        igemm(a0, w, n, batch=b2, a1=a1, bias=bias, res=res, out=out, out_t=out_t, ln=ln, res_lo=res_lo, out_lo=out_lo, k8=k8,
+              gn_part=gn_part, **kw)
         o = lambda t, e: None if t is None else _off(t, e)  # noqa: E731
         igemm(_off(a0, b2 * hin * win * c0), w2, n, batch=batch - b2, a1=o(a1, b2 * hin * win * c1), bias=bias2,
               res=o(res, b2 * tok * ld_res), out=_off(out, b2 * tok * ldo), out_t=o(out_t, b2 * (n - ntr0_) * ld_t),
               ln=None if ln is None else (ln2[0], ln2[1], ln[2]), res_lo=o(res_lo, b2 * tok * ld_res),
-              out_lo=o(out_lo, b2 * tok * ldo), k8=None if k8 is None else (_off(k8[0], b2 * tok * k8[3]),) + tuple(k8[1:]), **kw)
+              out_lo=o(out_lo, b2 * tok * ldo), k8=None if k8 is None else (_off(k8[0], b2 * tok * k8[3]),) + tuple(k8[1:]),
+              gn_part=o(gn_part, (b2 * tok // 64) * 2 * n), **kw)
         return out
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
@@ -104,6 +106,12 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
             y = y + _mem(res_lo, (batch, tokens, ntr0), (tokens * ld_res, ld_res, 1)).float()
     o = _mem(out, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1))
     o.copy_(y)
+    if gn_part is not None:   # per 64-row granule and column: sum / sum of squares of the STORED (rounded) values
+        assert tokens % 64 == 0 and ntr0 == n and not out_f32 and k8 is None
+        v = o.float().reshape(batch * tokens // 64, 64, n)
+        pt = _mem(gn_part, (batch * tokens // 64, 2, n), (2 * n, n, 1))
+        pt[:, 0].copy_(v.sum(1))
+        pt[:, 1].copy_((v * v).sum(1))
     if out_lo is not None:   # what the fp16 store dropped (two-term residual stream)
         _mem(out_lo, (batch, tokens, ntr0), (tokens * ld_out, ld_out, 1)).copy_(y - o.float())
     return out
@@ -157,20 +165,43 @@ def groupnorm_ws_bytes(batch, hw, groups=32):
     return 1024
 
 
-def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None):
+# the emulated md_groupnorm "wants partials" wherever they are usable (hw % 64 == 0), so that the CPU tier exercises the
+# producer -> consumer plumbing of the partial statistics at the small test geometries too
+def groupnorm_wants_partials(batch, hw, c, groups=32):
+    return hw % 64 == 0 and c % groups == 0
+
+
+def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None, part0=None,
+              part1=None):
     if set2 is not None:
         b2, gamma2, beta2 = set2
         assert 0 < b2 < batch
         kw = dict(hw=hw, c0=c0, c1=c1, groups=groups, eps=eps, silu=silu)
-        groupnorm(x0, gamma, beta, out, ws, batch=b2, x1=x1, **kw)
+        o = lambda t, e: None if t is None else _off(t, e)  # noqa: E731
+        groupnorm(x0, gamma, beta, out, ws, batch=b2, x1=x1, part0=part0, part1=part1, **kw)
         groupnorm(_off(x0, b2 * hw * c0), gamma2, beta2, _off(out, b2 * hw * (c0 + c1)), ws, batch=batch - b2,
-                  x1=None if x1 is None else _off(x1, b2 * hw * c1), **kw)
+                  x1=None if x1 is None else _off(x1, b2 * hw * c1), part0=o(part0, (b2 * hw // 64) * 2 * c0),
+                  part1=o(part1, (b2 * hw // 64) * 2 * c1), **kw)
         return out
     xs = [_mem(x0, (batch, hw, c0), (hw * c0, c0, 1)).float()]
     if x1 is not None:
         xs.append(_mem(x1, (batch, hw, c1), (hw * c1, c1, 1)).float())
     x = torch.cat(xs, -1).transpose(1, 2)  # [B, C, HW]
-    y = F.group_norm(x, groups, gamma.float(), beta.float(), eps=eps)
+    if part0 is not None and (x1 is None or part1 is not None) and hw % 64 == 0:
+        # statistics from the producers' partials, NOT from x: a stale / misplaced partial buffer must show up as a wrong result
+        P = hw // 64
+        ps = [_mem(part0, (batch, P, 2, c0), (P * 2 * c0, 2 * c0, c0, 1))]
+        if x1 is not None:
+            ps.append(_mem(part1, (batch, P, 2, c1), (P * 2 * c1, 2 * c1, c1, 1)))
+        pc = torch.cat(ps, -1).sum(1)                       # [B, 2, C]
+        c, cpg = c0 + c1, (c0 + c1) // groups
+        sg = pc.reshape(batch, 2, groups, cpg).sum(-1) / (hw * cpg)
+        mu, var = sg[:, 0], (sg[:, 1] - sg[:, 0] ** 2).clamp_min(0)
+        xg = x.reshape(batch, groups, cpg, hw)
+        y = ((xg - mu[:, :, None, None]) * torch.rsqrt(var + eps)[:, :, None, None]).reshape(batch, c, hw)
+        y = y * gamma.float()[None, :, None] + beta.float()[None, :, None]
+    else:
+        y = F.group_norm(x, groups, gamma.float(), beta.float(), eps=eps)
     if silu:
         y = F.silu(y)
     c = c0 + c1
@@ -318,7 +349,7 @@ class _Event:
 def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
-    for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "layernorm", "nchw_to_nhwc_f16",
+    for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
                  "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -59,8 +59,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
-                                 34, 35, 36, 37])
+@pytest.mark.parametrize("cfg", [-1, 4, 5, 6, 7, 12, 13, 14, 15, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33])
 def test_igemm_conv(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cins, h, w, cout, k, stride, ups = case
@@ -132,32 +131,79 @@ def test_igemm_two_term_residual(dev, splitk):
     assert float(out_lo.float().abs().max()) <= 2.0 ** -11 * scale * 1.01
 
 
-@pytest.mark.parametrize("cfg", [34, 35, 36, 37])
-def test_igemm_m32_tiles_epilogues(dev, cfg):
-    """32x32x16-fragment tiles: GEGLU pairing inside a 32-row fragment, split-K slabs, two-term residual, per-column scale,
-    transposed V^T store, M and N tails."""
+# (config, k-groups) pairs the launcher instantiates: max_kg() in igemm.hip
+KG_CFGS = [(12, 2), (13, 2), (14, 2), (15, 2), (15, 4), (24, 2), (25, 2), (26, 2), (27, 2), (27, 4), (28, 2), (29, 2)]
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] in ("c3_s1", "c3_s2", "c3_up", "c3_cat", "c1_cat", "c3_big", "c3_odd")],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("cfg,kg", KG_CFGS)
+def test_igemm_conv_kgroups(dev, case, cfg, kg):
+    """k-groups (md_igemm force_kg): 2 / 4 four-wave groups of one workgroup share the K dimension of a tile, summed through LDS.
+    Same references and tolerance as test_igemm_conv; K from 1 k-tile (fewer tiles than groups) to 45."""
+    from magicdance_amd import ops, engine
+    name, b, cins, h, w, cout, k, stride, ups = case
+    xs = [_rand((b, c, h, w), 10 + i, dev) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    wt = _rand((cout, cin, k, k), 20, dev, scale=(cin * k * k) ** -0.5)
+    bias = _rand((cout,), 21, dev, 0.1)
+    x16 = [_nhwc16(x) for x in xs]
+    w16 = engine.pack_conv(wt, dev)
+    xin = torch.cat([x.half().float() for x in xs], 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wt.half().float(), bias, stride=stride, padding=k // 2)
+    ho, wo = ref.shape[2], ref.shape[3]
+    out = torch.empty((b, ho * wo, cout), dtype=F16, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    for sk in (1, 2):
+        out.fill_(7.0)
+        ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride, ups=ups,
+                  a1=x16[1] if len(cins) > 1 else None, c1=cins[1] if len(cins) > 1 else 0, bias=bias, out=out, ws=ws,
+                  force_cfg=cfg, force_kg=kg, force_splitk=sk)
+        assert _err(_nchw32(out, b, ho, wo), ref) <= 4e-3 * max(1.0, float(ref.abs().max())), (name, sk)
+    # repeated launches are bit-identical (fixed-order cross-group sum)
+    o2 = torch.empty_like(out)
+    ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride, ups=ups,
+              a1=x16[1] if len(cins) > 1 else None, c1=cins[1] if len(cins) > 1 else 0, bias=bias, out=o2, ws=ws,
+              force_cfg=cfg, force_kg=kg, force_splitk=2)
+    assert torch.equal(out, o2)
+
+
+@pytest.mark.parametrize("cfg,kg", [(15, 4), (27, 4), (28, 2), (12, 2), (25, 2)])
+def test_igemm_kgroups_epilogues(dev, cfg, kg):
+    """k-groups with every epilogue family: GEGLU, fused q|k + V^T with column scale, two-term residual with split-K on top,
+    folded LayerNorm (the groups' row sums are combined too)."""
     from magicdance_amd import ops, engine
     b, n, c = 2, 200, 128   # M = 400: not a multiple of the tile
     x = _rand((b, n, c), 1, dev).to(F16)
     xr = x.float()
-    w1, b1 = _rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1)
-    wp, bp = engine.pack_geglu(w1, b1, dev)
-    og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
-    ops.igemm(x, wp, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og, ld_out=4 * c,
-              force_cfg=cfg)
-    hr = xr @ w1.half().float().t() + b1
-    a, g = hr.chunk(2, dim=-1)
-    assert _err(og, a * F.gelu(g)) <= 6e-3
-    # fused q|k + V^T store with the q columns scaled, N = 3c = 384 (tail for the 160-wide tiles)
+    if cfg in (15, 28, 12):   # tiles whose per-wave fragment count along N is even
+        w1, b1 = _rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1)
+        wp, bp = engine.pack_geglu(w1, b1, dev)
+        og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
+        ops.igemm(x, wp, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og, ld_out=4 * c,
+                  force_cfg=cfg, force_kg=kg)
+        hr = xr @ w1.half().float().t() + b1
+        a, g = hr.chunk(2, dim=-1)
+        assert _err(og, a * F.gelu(g)) <= 6e-3
     wq = _rand((3 * c, c), 2, dev, c ** -0.5)
     qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
     vt = torch.zeros((b, c, 208), dtype=F16, device=dev)
     ops.igemm(x, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
-              n_tr_begin=2 * c, ld_t=208, col_scale=(0.25, c), force_cfg=cfg)
+              n_tr_begin=2 * c, ld_t=208, col_scale=(0.25, c), force_cfg=cfg, force_kg=kg)
     ref = xr @ wq.half().float().t()
     assert _err(qk[..., :c], ref[..., :c] * 0.25) <= 4e-3 and _err(qk[..., c:], ref[..., c:2 * c]) <= 4e-3
     assert _err(vt[:, :, :n], ref[..., 2 * c:].transpose(1, 2)) <= 4e-3
-    # 3x3 conv, split-K, two-term residual
+    # folded LayerNorm: rows with mean 1 / std 3
+    xl = (_rand((b, n, c), 8, dev) * 3 + 1).to(F16)
+    gamma, beta = 1 + 0.1 * _rand((c,), 9, dev), 0.1 * _rand((c,), 10, dev)
+    wl, s1, s0 = engine.fold_layernorm(wq[:c], None, gamma, beta, dev)
+    ol = torch.empty((b, n, c), dtype=F16, device=dev)
+    ops.igemm(xl, wl, c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=ol, ln=(s1, s0, 1e-5), force_cfg=cfg, force_kg=kg)
+    refl = F.layer_norm(xl.float(), (c,), gamma, beta) @ wq[:c].t()
+    assert _err(ol, refl) <= 6e-3 * max(1.0, float(refl.abs().max()))
+    # 3x3 conv, split-K on top of the k-groups, two-term residual
     xc = _rand((2, 128, 8, 8), 5, dev)
     wt = _rand((128, 128, 3, 3), 6, dev, (128 * 9) ** -0.5)
     res32 = _rand((2, 128, 8, 8), 7, dev, 3.0)
@@ -169,8 +215,66 @@ def test_igemm_m32_tiles_epilogues(dev, cfg):
     ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     for sk in (1, 3):
         ops.igemm(_nhwc16(xc), engine.pack_conv(wt, dev), 128, batch=2, hin=8, win=8, hout=8, wout=8, c0=128, ksize=3, res=res_hi,
-                  ld_res=128, res_lo=res_lo, out=out, out_lo=out_lo, ws=ws, force_cfg=cfg, force_splitk=sk)
+                  ld_res=128, res_lo=res_lo, out=out, out_lo=out_lo, ws=ws, force_cfg=cfg, force_kg=kg, force_splitk=sk)
         assert _err(_nchw32(out.float() + out_lo.float(), 2, 8, 8), refc) <= 3e-5 * float(refc.abs().max()), sk
+
+
+PART_CASES = [
+    # name, B, Cin, H, W, Cout, k, batch2 (second parameter set from that sample on; 0: one set)
+    ("p_64x320", 2, 320, 16, 16, 320, 3, 0),     # hw = 256: four granules per sample
+    ("p_1x1", 3, 128, 8, 16, 192, 1, 0),         # hw = 128, N = 192 (tail of the 128 / 160-wide tiles)
+    ("p_dual", 3, 64, 8, 8, 128, 3, 2),          # hw = 64: one granule per sample; samples 2.. use the second weight set
+]
+
+
+@pytest.mark.parametrize("case", PART_CASES, ids=[c[0] for c in PART_CASES])
+@pytest.mark.parametrize("cfg,kg", [(-1, 0), (12, 1), (13, 1), (14, 1), (15, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (30, 1),
+                                    (33, 1), (27, 4), (25, 2), (7, 1), (4, 1)])
+def test_igemm_groupnorm_partials(dev, case, cfg, kg):
+    """md_igemm gn_part: per 64-row granule and column, sum and sum of squares of the fp16 values the call stored -- against the
+    sums of its own output (exact up to fp32 summation order), for every tile shape's wave layout."""
+    from magicdance_amd import ops, engine
+    name, b, cin, h, w, cout, k, b2 = case
+    x = _rand((b, cin, h, w), 1, dev)
+    wt = _rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5)
+    wt2 = _rand((cout, cin, k, k), 12, dev, (cin * k * k) ** -0.5)
+    bias, bias2 = _rand((cout,), 3, dev, 0.5), _rand((cout,), 13, dev, 0.5)
+    res = _nhwc16(_rand((b, cout, h, w), 4, dev))
+    hw = h * w
+    out = torch.empty((b, hw, cout), dtype=F16, device=dev)
+    part = torch.full((b * hw // 64, 2, cout), float("nan"), dtype=F32, device=dev)
+    set2 = (b2, engine.pack_conv(wt2, dev), bias2, None) if b2 else None
+    ops.igemm(_nhwc16(x), engine.pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, bias=bias,
+              res=res, ld_res=cout, out=out, gn_part=part, force_cfg=cfg, force_kg=kg, set2=set2)
+    v = out.float().reshape(b * hw // 64, 64, cout)
+    assert bool(torch.isfinite(part).all())
+    assert _err(part[:, 0], v.sum(1)) <= 2e-4 * float(v.abs().sum(1).max())
+    assert _err(part[:, 1], (v * v).sum(1)) <= 2e-4 * float((v * v).sum(1).max())
+    # an in-place add into the first sample only refreshes exactly that sample's granules
+    before = part.clone()
+    ops.igemm(_nhwc16(x)[:1], engine.pack_conv(wt, dev), cout, batch=1, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, bias=bias,
+              res=out[:1], ld_res=cout, out=out[:1], gn_part=part, force_cfg=cfg, force_kg=kg)
+    v = out.float().reshape(b * hw // 64, 64, cout)
+    assert _err(part[:, 0], v.sum(1)) <= 2e-4 * float(v.abs().sum(1).max())
+    assert torch.equal(part[hw // 64:], before[hw // 64:])
+
+
+def test_igemm_groupnorm_partials_rejected(dev):
+    """gn_part needs the plain fp16 epilogue, whole granules per sample and K in one workgroup."""
+    from magicdance_amd import ops, _lib
+    x = torch.zeros((1, 100, 64), dtype=F16, device=dev)
+    w = torch.zeros((64, 64), dtype=F16, device=dev)
+    part = torch.zeros((2, 2, 64), dtype=F32, device=dev)
+    with pytest.raises(_lib.MagicDanceHipError):   # 100 tokens: not a multiple of 64
+        ops.igemm(x, w, 64, batch=1, hin=1, win=100, hout=1, wout=100, c0=64, out=torch.empty_like(x), gn_part=part)
+    x = torch.zeros((1, 128, 64), dtype=F16, device=dev)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    with pytest.raises(_lib.MagicDanceHipError):   # forced split-K
+        ops.igemm(x, w, 64, batch=1, hin=1, win=128, hout=1, wout=128, c0=64, out=torch.empty_like(x), gn_part=part, ws=ws,
+                  force_splitk=2)
+    with pytest.raises(_lib.MagicDanceHipError):   # fp32 output
+        ops.igemm(x, w, 64, batch=1, hin=1, win=128, hout=1, wout=128, c0=64, out=torch.empty((1, 128, 64), dtype=F32, device=dev),
+                  out_f32=True, gn_part=part)
 
 
 def test_igemm_linear_f32_transposed_geglu(dev):
@@ -399,6 +503,50 @@ def test_groupnorm(dev, shape, silu):
     assert _err(_nchw32(out, b, h, w), ref) <= 4e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 320, 64, 64, None), (3, 640, 64, 64, 320), (1, 960, 64, 64, 640), (2, 1280, 32, 64, None),
+                                   (1, 128, 128, 128, None), (2, 512, 96, 96, 256)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_from_partials(dev, shape, silu):
+    """md_groupnorm part0 / part1: statistics folded from per-granule partials (as md_igemm gn_part writes them) instead of a pass
+    over x; one- and two-source, groups that straddle the two sources (960 = 640 + 320 channels: 30 per group), second affine set.
+    Partials are built from x itself here, so the result must agree with the statistics-pass form to fp32 summation order."""
+    from magicdance_amd import ops
+    b, c, h, w, c0 = shape
+    hw = h * w
+    x = _rand((b, c, h, w), 1, dev) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * _rand((c,), 2, dev), 0.1 * _rand((c,), 3, dev)
+    gamma2, beta2 = 1 + 0.1 * _rand((c,), 4, dev), 0.1 * _rand((c,), 5, dev)
+    eps = 1e-5 if silu else 1e-6
+    x16 = _nhwc16(x)
+    assert ops.groupnorm_wants_partials(b, hw, c, 32)
+
+    def parts(t):
+        v = t.float().reshape(b * hw // 64, 64, t.shape[-1])
+        return torch.stack([v.sum(1), (v * v).sum(1)], 1).contiguous()
+
+    out = torch.empty((b, hw, c), dtype=F16, device=dev)
+    ref = torch.empty_like(out)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    set2 = (b - 1, gamma2, beta2) if b > 1 else None
+    if c0 is None:
+        ops.groupnorm(x16, gamma, beta, ref, ws, batch=b, hw=hw, c0=c, eps=eps, silu=silu, set2=set2)
+        ops.groupnorm(x16, gamma, beta, out, ws, batch=b, hw=hw, c0=c, eps=eps, silu=silu, set2=set2, part0=parts(x16))
+    else:
+        xa, xb = x16[..., :c0].contiguous(), x16[..., c0:].contiguous()
+        ops.groupnorm(xa, gamma, beta, ref, ws, batch=b, hw=hw, c0=c0, x1=xb, c1=c - c0, eps=eps, silu=silu, set2=set2)
+        ops.groupnorm(xa, gamma, beta, out, ws, batch=b, hw=hw, c0=c0, x1=xb, c1=c - c0, eps=eps, silu=silu, set2=set2,
+                      part0=parts(xa), part1=parts(xb))
+    assert _err(out, ref) <= 2e-3          # one fp16 ulp of O(1..4) outputs: the statistics differ in summation order only
+    gref = F.group_norm(x.half().float()[:b - 1 if set2 else b], 32, gamma, beta, eps=eps)
+    gref = F.silu(gref) if silu else gref
+    assert _err(_nchw32(out[:b - 1 if set2 else b], b - 1 if set2 else b, h, w), gref) <= 4e-3
+    # the partials are what is used: scaled partials must change the result
+    bad = torch.empty_like(out)
+    if c0 is None:
+        ops.groupnorm(x16, gamma, beta, bad, ws, batch=b, hw=hw, c0=c, eps=eps, silu=silu, set2=set2, part0=parts(x16) * 4)
+        assert _err(bad, ref) > 0.05
+
+
 @pytest.mark.parametrize("c", [64, 320, 640, 1280])
 def test_layernorm(dev, c):
     from magicdance_amd import ops
@@ -594,7 +742,7 @@ def test_igemm_folded_layernorm_geglu_and_transposed(dev):
 
 @pytest.mark.parametrize("case", [("c3", 3, 2, 320, 8, 8, 128, 3, 1), ("c3_ragged", 3, 2, 64, 6, 6, 96, 3, 1), ("c1", 6, 4, 320, 16, 16, 320, 1, 1),
                                   ("down", 3, 2, 128, 16, 16, 128, 3, 2), ("stem", 3, 2, 8, 16, 16, 64, 3, 1), ("big", 3, 2, 320, 64, 64, 320, 3, 1)])
-@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (12, 1), (25, 1), (27, 1), (29, 2), (32, 1), (15, 3), (34, 1), (3, 1), (7, 1)])
+@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (12, 1), (25, 1), (27, 1), (29, 2), (32, 1), (15, 3), (7, 1)])
 def test_igemm_second_parameter_set(dev, case, cfg, splitk):
     """md_igemm w2 / bias2 / batch2 (ABI v3): samples >= batch2 use the second weight / bias set.  One launch must reproduce, BIT
     FOR BIT, two launches on the two sample ranges with the same tile config (the tiles of the second set start at its first row;
@@ -603,7 +751,7 @@ def test_igemm_second_parameter_set(dev, case, cfg, splitk):
     name, b, b2, cin, h, w, cout, k, stride = case
     if cin % 64 and cfg >= 12:
         pytest.skip("buffer loader needs 64-channel k-tiles")
-    if cfg in (3, 7) and splitk == 1 and name == "big":
+    if cfg == 7 and splitk == 1 and name == "big":
         pytest.skip("slow register-staged tiles on the big case")
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
     x = _nhwc16(_rand((b, cin, h, w), 1, dev))

@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="stop at the latents (skip the first-stage decode)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every DDIM step un-captured (same launches, no HIP graph): the form the rocprofv3 --pmc passes of "
+                         "tools/run_profiles.sh run on (the counter tool does not survive graph replays of the linear step graph)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +159,8 @@ def main():
     cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get((fpg, world), "configs[3]" if (fpg == 8 and world > 1) else "custom")
     inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
     runner = parallel.FrameShardedSampler(model, rank=rank, world=world)
+    if args.no_graph:
+        runner._runner().use_graph = False
     my = slice(rank * fpg, (rank + 1) * fpg)
     pose, ctx, ref, x_T = inp["pose"][my].contiguous(), inp["ctx"], inp["ref"], inp["x_T"].repeat(fpg, 1, 1, 1)
 
@@ -209,14 +214,16 @@ def main():
         # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS
         # workload -- the 50-step batch --, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
         traffic, traffic_src = None, None
-        for cand in ("round2_pmc_summary.json", "round1_pmc_summary.json"):
+        traffic_kind = "measured"
+        for cand in ("round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), cand
-                # the counters were collected on a launch mix with more (smaller) igemm launches per batch (pose ControlNet on its
-                # own stream): same bytes per batch, re-expressed per launch of THIS run's mix
-                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"]:
+                # round 3: the counters are collected on THIS launch mix (bench.py --no-graph: the default merged pass, un-captured).
+                # An older summary (other launch mix) is re-expressed per launch of this run's mix and labelled as derived.
+                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"] and pmc["igemm_launches_per_batch"] != ig["launches"]:
                     traffic = traffic * pmc["igemm_launches_per_batch"] / ig["launches"]
+                    traffic_kind = f"derived: bytes per batch of a {pmc['igemm_launches_per_batch']}-launch mix over this run's launches"
                 if not (args.ddim_steps == 50 and fpg == 1 and args.size == 64 and not args.sequence):
                     traffic, traffic_src = None, None   # the counters were collected on configs[1] only
                 break
@@ -231,8 +238,8 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one batch: reference-KV table pass + "
                            f"{ig['ddim_steps']} DDIM steps" + ("" if args.no_decode else " + first-stage decode") + ")", "achieved": ach,
                            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
-                           "traffic_unit": (f"bytes/launch (PMC, profiles/{traffic_src})" if traffic_src else
-                                            "null: the PMC passes (profiles/round2_pmc_summary.json) cover configs[1] only"),
+                           "traffic_unit": (f"bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_src}, {traffic_kind})" if traffic_src else
+                                            "null: the PMC passes (profiles/round3_pmc_summary.json) cover configs[1] only"),
                            "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
                            "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,

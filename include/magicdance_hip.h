@@ -185,8 +185,9 @@ typedef struct {
   const float* gamma2; const float* beta2;          /* ABI v3: samples b >= batch2 use this affine pair (see md_igemm batch2) */
   int32_t batch2;                                   /* <= 0 or gamma2 == NULL: one parameter set */
   /* ABI v4: partial statistics of x0 / x1 as written by the md_igemm calls that produced them (md_igemm_params.gn_part: fp32
-   * [batch * hw / 64][2][c0 or c1]).  When given for every source (and hw % 64 == 0) the statistics pass over x is skipped: one
-   * launch folds the partials of its (sample, groups) in fixed order and normalises.  NULL: statistics are computed from x. */
+   * [batch * hw / 64][2][c0 or c1]).  When given for every source (and hw % 64 == 0) the statistics pass over x is replaced by a
+   * fold of the partials (~6 % of the bytes of x, fixed order) ahead of the normalising pass.  NULL: statistics are computed from
+   * x.  Small slices (one launch owns whole groups and keeps them in registers) ignore the partials. */
   const float* part0; const float* part1;
 } md_groupnorm_params;
 int md_groupnorm(const md_groupnorm_params* p, void* stream);

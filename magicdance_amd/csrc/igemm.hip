@@ -694,10 +694,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
     const half_t* __restrict__ const rlp = e_res_lo;
     half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
     half_t* __restrict__ const olp = e_out_lo;
-    // GroupNorm partials of this wave's rows (all inside ONE 64-row granule: WTM <= 64, tiles start on multiples of 64)
-    f4 ps[NF], pq[NF];
-#pragma unroll
-    for (int i = 0; i < NF; ++i) ps[i] = pq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    // GroupNorm partials: per 16-row fragment the lanes' values are summed over the fragment's rows at once (DPP, fixed order) and
+    // parked in LDS [wave row][fragment][column][sum | sumsq] -- nothing is carried in registers across fragments (accumulating in
+    // registers cost 40 VGPRs and a wave per SIMD of occupancy on the 160-wide tiles, whether or not partials were requested)
+    float* const pred = reinterpret_cast<float*>(smem);
+    if (e_part) __syncthreads();   // every wave is done with the k-loop's (and the k-group reduction's) LDS reads
     if (epi) {
 #pragma unroll
       for (int j = 0; j < MF; ++j) {
@@ -728,11 +729,12 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (m >= Mlim) continue;
+        const bool row_ok = m < Mlim;
+        if (!row_ok && !e_part) continue;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
           const int n = n0 + wn * WTN + i * 16 + lg * 4;
-          if (n >= g.N) continue;
+          if (n >= g.N) continue;   // (uniform over the 16 lanes of a DPP row: they share lg)
           f4 v = acc[i][j];
           v += bv[i];
           if (n < e_col_scale_end) v *= e_col_scale;
@@ -747,55 +749,47 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
           h4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
-          if (olp) {
-            h4 l;
+          if (row_ok) {
+            *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
+            if (olp) {
+              h4 l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
-            *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
+              for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
+              *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
+            }
           }
-          if (e_part) {   // statistics of the value the GroupNorm will read: the rounded fp16 hi term
+          if (e_part) {   // statistics of the value the GroupNorm will read: the rounded fp16 hi term (rows past the end: 0)
+            float sv[4], qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float f = (float)o[e];
-              ps[i][e] += f;
-              pq[i][e] += f * f;
+              const float f = row_ok ? (float)o[e] : 0.f;
+              sv[e] = row16_sum(f);
+              qv[e] = row16_sum(f * f);
+            }
+            if (lr == 0) {
+              float* d = pred + (((wm * MF + j) * BN) + wn * WTN + i * 16 + lg * 4) * 2;
+              *reinterpret_cast<f4*>(d) = f4{sv[0], qv[0], sv[1], qv[1]};
+              *reinterpret_cast<f4*>(d + 4) = f4{sv[2], qv[2], sv[3], qv[3]};
             }
           }
         }
       }
     }
     if (e_part) {
-      // lane -> 16-row sum (DPP, fixed order) -> LDS [wave row][column][sum | sumsq] -> per 64-row granule and column, fixed order
-      float* const pred = reinterpret_cast<float*>(smem);
-      __syncthreads();   // the k-loop's / the k-group reduction's LDS reads are over
-      if (epi) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ps[i][e] = row16_sum(ps[i][e]);
-            pq[i][e] = row16_sum(pq[i][e]);
-          }
-          if (lr == 0) {
-            const int col = wn * WTN + i * 16 + lg * 4;
-            *reinterpret_cast<f4*>(pred + (wm * BN + col) * 2) = f4{ps[i][0], pq[i][0], ps[i][1], pq[i][1]};
-            *reinterpret_cast<f4*>(pred + (wm * BN + col) * 2 + 4) = f4{ps[i][2], pq[i][2], ps[i][3], pq[i][3]};
-          }
-        }
-      }
       __syncthreads();
-      if (epi && tid < BN && n0 + tid < g.N) {
+      if (epi && tid < BN && n0 + tid < g.N) {   // per 64-row granule and column: wave rows, then fragments, in fixed order
         constexpr int WPG = 64 / WTM > WAVES_M ? WAVES_M : 64 / WTM;   // wave rows per granule
 #pragma unroll
         for (int gi = 0; gi < (BM + 63) / 64; ++gi) {
           if (m0 + gi * 64 >= Mlim) break;
           float s = 0.f, q = 0.f;
 #pragma unroll
-          for (int w2 = 0; w2 < WPG; ++w2) {
-            s += pred[((gi * WPG + w2) * BN + tid) * 2];
-            q += pred[((gi * WPG + w2) * BN + tid) * 2 + 1];
-          }
+          for (int w2 = 0; w2 < WPG; ++w2)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+              s += pred[(((gi * WPG + w2) * MF + j) * BN + tid) * 2];
+              q += pred[(((gi * WPG + w2) * MF + j) * BN + tid) * 2 + 1];
+            }
           float* dst = e_part + ((long long)(m0 / 64 + gi) * 2) * g.N + n0 + tid;
           dst[0] = s;
           dst[g.N] = q;
@@ -979,7 +973,7 @@ int validate(const md_igemm_params* p) {
 
 // Measured-best (config, split-K) per layer shape, generated on an MI355X by tools/tune_igemm.py
 struct TunedEntry {
-  int m, n, k, ksize, stride, ups, cfg, split, kg;   // kg 0 (entries older than the k-groups): the rule in choose() decides
+  int m, n, k, ksize, stride, ups, cfg, split, kg;   // kg 0: an entry older than the k-groups (= 1)
 };
 const TunedEntry kTuned[] = {
 #include "igemm_tuned.inc"
@@ -1008,7 +1002,7 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
         if (ok_split && ok_buf && ok_act && ok_ln && cfg_exists(t->cfg)) {
           *cfg_out = t->cfg;
           *split_out = t->split;
-          *kg_out = t->kg;
+          *kg_out = t->kg > 0 ? t->kg : 1;   // a measured (config, split): entries older than the k-groups keep their 4-wave form
           return;
         }
       }
@@ -1049,8 +1043,9 @@ void choose(const md_igemm_params* p, long long M, int N, int K, long long ws_by
   *split_out = bs;
 }
 
-// k-groups for a (config, split) that carries no measured choice: turn global split-K into in-workgroup k-groups where the
-// config has them (no slabs, no reduce launch), and give grids that leave CUs without a second workgroup more waves per tile.
+// k-groups for a shape the tuned table does not hold (the time model above chose config and split): turn global split-K into
+// in-workgroup k-groups where the config has them (no slabs, no reduce launch), and give grids that leave CUs without a second
+// workgroup more waves per tile.
 int default_kg(int cfg, int* split, long long tiles, int nk, bool allow) {
   const int mk = allow ? max_kg(cfg) : 1;
   if (mk == 1) return 1;

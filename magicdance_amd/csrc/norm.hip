@@ -291,96 +291,40 @@ __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int
 
 // GroupNorm from PRODUCER partials (round 3; the ResBlock's "conv + GroupNorm + SiLU" fusion): the md_igemm that wrote x also
 // wrote, per 64-row granule and channel, the sum and the sum of squares of the fp16 values it stored (md_igemm_params.gn_part), so
-// the statistics pass over x disappears: a block = (row chunk, gper whole groups, sample) folds the partials of its groups
-// (hw / 64 granules x gper * cpg channels, fixed order -> deterministic) while its rows are already in flight, then normalises.
-// Two-source concat: channel ca < c0 reads part0 / x0, the rest part1 / x1 (a group may straddle the two).
-constexpr int GN_PART_MAXV = 8;
-__global__ __launch_bounds__(GN_SMALL_THREADS) void gn_part_apply(const GnArgs g, const float* __restrict__ part0,
-                                                                   const float* __restrict__ part1, int gper, int cw8, int rows_per_block) {
-  __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
-  __shared__ float stat[2 * GN_GPER_MAX];  // mean[gper], rstd[gper]
+// the statistics pass over x disappears.  gn_finalize folds the partials of one (sample, group) -- hw / 64 granules x cpg
+// channels x 2, about 6 % of the tensor's bytes in total, fixed order -> deterministic -- into the (sum, sumsq) pair gn_apply reads
+// (its workspace format with ONE chunk per sample); gn_apply then streams x fully coalesced, exactly as after gn_stats.
+// (A single-launch form -- every apply block folding the partials of its own groups -- was built first and measured no faster
+//  than stats + apply at one frame and 1.6 % slower end to end at 8: its blocks own 80-byte row slices, i.e. poorly coalesced
+//  reads, or else re-read the whole partial table per block.)
+// Two-source concat: channel ca < c0 reads part0, the rest part1 (a group may straddle the two).
+__global__ __launch_bounds__(256) void gn_finalize(const GnArgs g, const float* __restrict__ part0, const float* __restrict__ part1) {
+  __shared__ float red[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z;
-  const int v = tid % cw8, pl = tid / cw8, ps = GN_SMALL_THREADS / cw8;  // fixed vector column, pixel lane, pixel stride
-  const bool active = pl < ps;
-  const int cbase = blockIdx.y * gper * g.cpg;
-  const int c = cbase + v * 8;
-  const bool first = c < g.c0;
-  const half_t* src = first ? g.x0 + c : g.x1 + (c - g.c0);
-  const long long cs = first ? g.c0 : g.c1;
-  const long long pix0 = (long long)b * g.hw;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(g.hw, r0 + rows_per_block);
-  // (1) this thread's rows: all loads in flight before anything is consumed
-  h8 x[GN_PART_MAXV];
-#pragma unroll
-  for (int i = 0; i < GN_PART_MAXV; ++i) {
-    const int p = r0 + pl + i * ps;
-    if (active && p < r1) x[i] = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
-  }
-  // (2) partials of this block's channels: thread = (channel cl, granule lane); granules of sample b are rows b*P .. of the table
-  const int cw = gper * g.cpg, P = g.hw >> 6, pls = GN_SMALL_THREADS / cw;
-  const int cl = tid % cw, pg = tid / cw;
+  const int grp = blockIdx.x, b = blockIdx.y;
+  const int P = g.hw >> 6;
+  const int lanes = 256 / g.cpg;                 // granule lanes (cpg <= 128, launcher-checked)
+  const int cl = tid % g.cpg, pg = tid / g.cpg;
   float s = 0.f, q = 0.f;
-  if (pg < pls) {
-    const int ca = cbase + cl;
+  if (pg < lanes) {
+    const int ca = grp * g.cpg + cl;
     const bool f0 = ca < g.c0;
     const float* pt = f0 ? part0 + ca : part1 + (ca - g.c0);
     const long long pc = f0 ? g.c0 : g.c1;
-    for (int gr = pg; gr < P; gr += pls) {
+    for (int gr = pg; gr < P; gr += lanes) {
       const float* row = pt + ((long long)b * P + gr) * 2 * pc;
       s += row[0];
       q += row[pc];
     }
   }
-  const int lgk = cl / g.cpg;   // local group of this thread's partial channel
-  for (int k = 0; k < gper; ++k) {
-    float a = (pg < pls && lgk == k) ? s : 0.f;
-    float bq = (pg < pls && lgk == k) ? q : 0.f;
-    a = md::wave_sum(a);
-    bq = md::wave_sum(bq);
-    if (lane == 0) {
-      red[wave][2 * k] = a;
-      red[wave][2 * k + 1] = bq;
-    }
+  s = md::wave_sum(s);
+  q = md::wave_sum(q);
+  if (lane == 0) {
+    red[wave][0] = s;
+    red[wave][1] = q;
   }
   __syncthreads();
-  if (tid < gper) {
-    float sm = 0.f, sq = 0.f;
-    for (int w = 0; w < GN_SMALL_THREADS / 64; ++w) {
-      sm += red[w][2 * tid];
-      sq += red[w][2 * tid + 1];
-    }
-    const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
-    const float mu = sm * inv_n;
-    stat[tid] = mu;
-    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(sq * inv_n - mu * mu, 0.f) + g.eps);
-  }
-  __syncthreads();
-  if (!active) return;
-  float sc[8], sh[8];
-  const float* gamma = b >= g.batch2 ? g.gamma2 : g.gamma;
-  const float* beta = b >= g.batch2 ? g.beta2 : g.beta;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int lge = (v * 8 + e) / g.cpg;
-    sc[e] = stat[GN_GPER_MAX + lge] * gamma[c + e];
-    sh[e] = beta[c + e] - stat[lge] * sc[e];
-  }
-  half_t* dst = g.out + c;
-#pragma unroll
-  for (int i = 0; i < GN_PART_MAXV; ++i) {
-    const int p = r0 + pl + i * ps;
-    if (p < r1) {
-      h8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float y = (float)x[i][e] * sc[e] + sh[e];
-        if (g.silu) y = md::silu_f(y);
-        o[e] = (half_t)y;
-      }
-      *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
-    }
-  }
+  if (tid < 2) g.ws[((long long)b * g.groups + grp) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // whole groups per block such that the block's channel slice is a multiple of 8 channels (16-byte vectors)
@@ -401,10 +345,8 @@ inline bool gn_small_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
   return gn_group_block(cpg, groups, gper, cw8) && (long long)hw * *gper * cpg * 2 <= g_gn_small_bytes &&
          hw <= GN_SMALL_MAXV * (GN_SMALL_THREADS / *cw8);
 }
-// producer partials usable: 64-row granules per sample, group blocks of whole 16-byte vectors
-inline bool gn_part_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
-  return (hw & 63) == 0 && gn_group_block(cpg, groups, gper, cw8) && *gper * cpg <= GN_SMALL_THREADS;
-}
+// producer partials usable: whole 64-row granules per sample, a group's channels fit one finalize block
+inline bool gn_part_ok(int hw, int cpg) { return (hw & 63) == 0 && cpg <= 128; }
 
 // stats grid geometry shared by the launcher and the workspace query
 inline void gn_geometry(int batch, int hw, int c, int* ty, int* pix_per_chunk, int* nchunks) {
@@ -487,7 +429,7 @@ extern "C" int md_groupnorm_wants_partials(int32_t batch, int32_t hw, int32_t c,
   if (groups <= 0 || c <= 0 || c % groups) return 0;
   int gper = 1, cw8 = 1;
   if (gn_small_ok(hw, c / groups, groups, &gper, &cw8)) return 0;
-  return gn_part_ok(hw, c / groups, groups, &gper, &cw8) ? 1 : 0;
+  return gn_part_ok(hw, c / groups) ? 1 : 0;
 }
 
 extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
@@ -533,18 +475,17 @@ extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
       MD_HIP_CHECK(hipGetLastError());
       return MD_OK;
     }
-    if (p->part0 && (p->c1 == 0 || p->part1) && gn_part_ok(p->hw, g.cpg, p->groups, &gper, &cw8)) {
-      const int rows_per_block = GN_PART_MAXV * (GN_SMALL_THREADS / cw8);
-      hipLaunchKernelGGL(gn_part_apply, dim3((p->hw + rows_per_block - 1) / rows_per_block, p->groups / gper, g.batch),
-                         dim3(GN_SMALL_THREADS), 0, s, g, p->part0, p->part1 ? p->part1 : p->part0, gper, cw8, rows_per_block);
-      MD_HIP_CHECK(hipGetLastError());
-      return MD_OK;
-    }
   }
-  const int threads = g.ch8 * g.ty;
-  const size_t lds1 = 2 * (size_t)g.ty * c * sizeof(float);
-  hipLaunchKernelGGL(gn_stats, dim3(g.nchunks, g.batch), dim3(threads < 64 ? 64 : threads), lds1, s, g);
-  MD_HIP_CHECK(hipGetLastError());
+  if (p->part0 && (p->c1 == 0 || p->part1) && gn_part_ok(p->hw, g.cpg)) {
+    g.nchunks = 1;   // one (sum, sumsq) pair per (sample, group), folded from the producers' partials
+    hipLaunchKernelGGL(gn_finalize, dim3(p->groups, g.batch), dim3(256), 0, s, g, p->part0, p->part1 ? p->part1 : p->part0);
+    MD_HIP_CHECK(hipGetLastError());
+  } else {
+    const int threads = g.ch8 * g.ty;
+    const size_t lds1 = 2 * (size_t)g.ty * c * sizeof(float);
+    hipLaunchKernelGGL(gn_stats, dim3(g.nchunks, g.batch), dim3(threads < 64 ? 64 : threads), lds1, s, g);
+    MD_HIP_CHECK(hipGetLastError());
+  }
   const long long items = (long long)p->hw * g.ch8;
   const size_t lds2 = (2 * (size_t)c + 2 * (size_t)p->groups + 16 * (size_t)p->groups) * sizeof(float);
   hipLaunchKernelGGL(gn_apply, dim3((unsigned)((items + GN_ITEMS - 1) / GN_ITEMS), g.batch), dim3(256), lds2, s, g);

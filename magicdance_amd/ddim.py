@@ -196,8 +196,7 @@ class DDIMSampler_ReferenceOnly(object):
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            table = os.environ.get("MD_BANK_MODE", "table") != "inline"
-            st.prepare(c, img, self, scale, table_mode=table)
+            st.prepare(c, img, self, scale, table_mode=True)
 
             def on_step(i):
                 index = total - i - 1
@@ -218,17 +217,14 @@ class FusedStepRunner:
     """Owns the persistent device buffers of the fused step and its captured HIP graph (re-used across frames and
     sample_log calls while shapes / context / step count stay the same).
 
-    bank modes:
-      inline : the appearance net runs inside every step graph on a forked stream (MD_BANK_MODE=inline; also what the
-               generic per-call route does)
-      table  : (default) with ``wonoise`` the bank depends on (ref, t, ctx) only, never on the frame or on x_t, so the
-               banks of all S steps are computed BEFORE the loop: the appearance net runs on batches of ``bank_chunk``
-               timesteps at once (big, MFMA-efficient launches instead of S batch-1 passes) and the UNet's own to_k / to_v
-               of every bank entry are applied there too.  ``bank_table`` holds, per bank entry, K [S, bref, n, c] and
-               V^T [S, bref, c, ldv] (46 MB fp16 per step at 512x512, 2.3 GB for 50 steps); the step graph gathers row
-               ``counter`` into ``bank_cur`` with one md_gather_rows launch and skips the appearance net and the bank
-               projections.  The same table serves multi-GPU frame sharding (equal row blocks computed per rank and exchanged
-               with RCCL all-gathers, magicdance_amd/parallel.py) and multi-frame sequences sharing one reference image.
+    With ``wonoise`` the appearance bank depends on (ref, t, ctx) only, never on the frame or on x_t, so the banks of all S
+    steps are computed BEFORE the loop (the reference-KV table): the appearance net runs on batches of ``bank_chunk``
+    timesteps at once (big, MFMA-efficient launches instead of S batch-1 passes) and the UNet's own to_k / to_v of every bank
+    entry are applied there too.  ``bank_table`` holds, per bank entry, K [S, bref, n, c] and V^T [S, bref, c, ldv] (46 MB fp16
+    per step at 512x512, 2.3 GB for 50 steps); the step graph gathers row ``counter`` into ``bank_cur`` with one
+    md_gather_rows launch and contains neither the appearance net nor the bank projections.  The same table serves multi-GPU
+    frame sharding (equal row blocks computed per rank and exchanged with RCCL all-gathers, magicdance_amd/parallel.py) and
+    multi-frame sequences sharing one reference image.
     """
 
     def __init__(self, model):
@@ -236,44 +232,35 @@ class FusedStepRunner:
         self.key = None
         self.graph = None
         self.use_graph = True
-        self.table_mode = False
-        # (a high-priority step stream was measured SLOWER: 2.05 vs 2.23 frames/s with the table pass overlapped)
-        self.stream = torch.cuda.Stream(device=model.device, priority=int(os.environ.get("MD_STEP_PRIORITY", "0")))
-        # independent network passes of one step run on forked streams inside the captured graph:
-        #   0 serial | 1 appearance || pose, then UNet(cond+uncond batched) | 2 appearance || pose || UNet-uncond, then UNet-cond
-        #   3 appearance || pose || UNet, the UNet waiting per bank entry (event) and for the pose residuals at its middle block
-        self.overlap = int(os.environ.get("MD_OVERLAP", "3"))
-        self.bank_events = None
-        self.bank_chunk = int(os.environ.get("MD_BANK_CHUNK", "16"))   # appearance samples per batched table pass
+        self.table_mode = True
+        self.stream = torch.cuda.Stream(device=model.device)
+        self.bank_chunk = 16      # appearance samples (timesteps x reference latents) per batched table pass
         self.table_stream = torch.cuda.Stream(device=model.device)      # the table pass overlaps the first steps of the loop
-        # zero-conv + residual add as one in-place epilogue.  Built and measured: 13 launches fewer per step but SLOWER
-        # (2.48 vs 2.55 frames/s at configs[1]): a zero-conv may overwrite a skip only after the UNet's next block has read it, so the
-        # pose stream is throttled to the UNet's pace and its tail lands on the critical path.  Off by default (MD_FUSE_POSE=1 enables).
-        self.fuse_pose = os.environ.get("MD_FUSE_POSE", "0") == "1"
         # The pose ControlNet as extra samples of the UNet's encoder launches (NetEngine.unet_pose; default).  MD_MERGE_POSE=0: its
-        # own ~110 launches on a concurrent stream (the round-1 / early round-2 form, kept for comparison).
+        # own ~110 launches on a concurrent stream (the round-1 / early round-2 form; tests check the two against each other).
         self.merge_pose = os.environ.get("MD_MERGE_POSE", "1") == "1"
-        self.table_chunks = int(os.environ.get("MD_TABLE_CHUNKS", "2"))  # sharded: all-gathers per table (2nd overlaps the loop)
+        self.table_chunks = 2     # sharded: all-gathers per table (the 2nd overlaps the loop)
         self.tkey = None
-        self.side = [torch.cuda.Stream(device=model.device) for _ in range(3)]
+        self.pose_stream = torch.cuda.Stream(device=model.device)
 
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
 
-    def plan_table(self, S, bref, world=1):
+    def plan_table(self, S, bref, world=1, sharded=None):
         """(rows per block, blocks) of the reference-KV table.  A block = ``per`` consecutive DDIM rows = one contiguous piece
         of memory: what one batched appearance pass produces and, sharded, what one rank contributes to a chunk's all-gather
         (chunk k = blocks [k*world, (k+1)*world), block k*world + r computed by rank r).  world 1: per = the appearance batch
         (``bank_chunk`` samples); world > 1: S rows split into ``table_chunks`` all-gathers so that the second one overlaps the
         first steps of the loop."""
-        if world == 1:
+        sharded = world > 1 if sharded is None else sharded   # (a 1-rank group may run the sharded form: tests, --gpus 1 RCCL checks)
+        if not sharded:
             per = max(1, min(S, self.bank_chunk // bref))
         else:
             per = max(1, -(-S // (world * max(1, self.table_chunks))))
         nblocks = -(-(-(-S // per)) // world) * world
         return per, nblocks
 
-    def prepare(self, c, x_T, sampler, scale, table_mode=False, world=1):
+    def prepare(self, c, x_T, sampler, scale, table_mode=False, world=1, sharded=None):
         """Per-batch buffers (x, pose features, schedule tables; keyed on the batch geometry) and -- in table mode -- the
         reference-KV table (keyed on the reference / schedule geometry only, so a sequence sampled in batches of different
         sizes keeps one table)."""
@@ -298,7 +285,7 @@ class FusedStepRunner:
         self.kv_app = app.context_kv(self._ctx_app)
         self.kv_pose = pose_e.context_kv(self._ctx_app if self._ctx_app.shape[0] in (1, b) else self._ctx_src)
         self.kv_unet = unet.context_kv(self._ctx_unet)
-        self.kv_merged = unet.merged_context_kv(self.kv_unet, self.kv_pose, b) if self.merge_pose and self.overlap == 3 else None
+        self.kv_merged = unet.merged_context_kv(self.kv_unet, self.kv_pose, b) if self.merge_pose else None
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
         bref = ref.shape[0]
@@ -307,7 +294,7 @@ class FusedStepRunner:
         if key != self.key:
             self._allocate(key, b, cch, hh, ww, S, bref, table_mode)
         if table_mode:
-            per, nblocks = self.plan_table(S, bref, world)
+            per, nblocks = self.plan_table(S, bref, world, sharded)
             from . import engine as _eng
             tkey = (cch, hh, ww, S, bref, per, nblocks, _eng.ATTN_FP8)
             if tkey != self.tkey:
@@ -455,7 +442,7 @@ class FusedStepRunner:
         r0 = k * world * self.per
         return min(self.S, r0), min(self.S, r0 + world * self.per)
 
-    def enqueue_chunk(self, k, rank=0, world=1, group=None):
+    def enqueue_chunk(self, k, rank=0, world=1, group=None, sharded=None):
         """Chunk k of the reference-KV table on the current stream: this rank's block (one batched appearance pass + the bank
         K / V^T projections), then -- sharded -- ONE RCCL all-gather of the chunk's ``world`` contiguous blocks, in place (the
         send buffer is this rank's block inside the receive buffer; every point-to-point xGMI link carries a different block at
@@ -464,37 +451,32 @@ class FusedStepRunner:
         r0, r1 = min(self.S, blk * self.per), min(self.S, (blk + 1) * self.per)
         if r1 > r0:
             self.compute_bank_rows(range(r0, r1))
-        if world > 1:
+        if world > 1 if sharded is None else sharded:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.table_block(k * world, world), self.table_block(blk), group=group)
 
-    def run_steps(self, rank=0, world=1, group=None, on_step=None, fill=True, steps=True):
+    def run_steps(self, rank=0, world=1, group=None, on_step=None, fill=True, steps=True, sharded=None):
         """The S-step loop on ``self.stream`` (current).  In table mode the table is (``fill``) produced chunk by chunk on
         ``table_stream`` AHEAD of the loop: chunk k + 1 (appearance pass and, sharded, its all-gather) is enqueued before the
         step graphs of chunk k, which wait on chunk k's event -- step i only needs row i, and the big launches of the table pass
         fill the CUs that the small launches of a step leave idle.  ``steps=False``: fill only (a rank with no frames still takes
         part in the collectives)."""
         S = self.S
-        if not (self.table_mode and fill):
+        if not fill:
             for i in range(S if steps else 0):
                 self.step()
                 if on_step:
                     on_step(i)
             return
-        overlap = os.environ.get("MD_TABLE_OVERLAP", "1") != "0"
 
         def enqueue(k):
-            if not overlap:
-                self.enqueue_chunk(k, rank, world, group)
-                return None
             with torch.cuda.stream(self.table_stream):
-                self.enqueue_chunk(k, rank, world, group)
+                self.enqueue_chunk(k, rank, world, group, sharded)
                 ev = torch.cuda.Event()
                 ev.record(self.table_stream)
             return ev
 
-        if overlap:
-            self.table_stream.wait_stream(torch.cuda.current_stream())   # earlier steps are done with the table; inputs in place
+        self.table_stream.wait_stream(torch.cuda.current_stream())   # earlier steps are done with the table; inputs in place
         nch = self.n_chunks(world)
         ev = enqueue(0)
         for k in range(nch):
@@ -521,99 +503,23 @@ class FusedStepRunner:
         arena.reset()
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
-        if self.table_mode:
-            ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
-                            self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
-        if self.overlap == 3:
-            s_app, s_pose, _ = self.side
-            if self.table_mode:
-                banks = self.bank_cur_kv
-                unet._bank_events = None
-            else:
-                from .nets import bank_shapes
-                shp = bank_shapes(app.cfg, (int(self.x.shape[2]), int(self.x.shape[3])))
-                if self.bank_events is None or len(self.bank_events) != len(shp):
-                    self.bank_events = [torch.cuda.Event() for _ in shp]
-                # the bank entries are written straight into fixed buffers so the UNet can be enqueued before they exist
-                if getattr(self, "_inline_bank", None) is None or self._inline_bank[0] != (self.ref.shape[0], tuple(shp)):
-                    bufs = [torch.empty((self.ref.shape[0], n, c), dtype=F16, device=self.x.device) for n, c in shp]
-                    from .engine import Act
-                    self._inline_bank = ((self.ref.shape[0], tuple(shp)),
-                                         [Act(t, self.ref.shape[0], 1, t.shape[1], t.shape[2]) for t in bufs])
-                banks = self._inline_bank[1]
-                s_app.wait_stream(main)
-                with torch.cuda.stream(s_app):
-                    app._bank_events = self.bank_events
-                    app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app, bank_out=banks)
-                    app._bank_events = None
-                unet._bank_events = self.bank_events
-            if self.merge_pose:
-                # the pose ControlNet rides in the UNet encoder's launches (second parameter set): no stream of its own
-                eps = unet.unet_pose(pose_e, self.x, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
-                                     self.emb_cur_pose, banks=banks, nread=b, only_mid_control=model.only_mid_control)
-            elif self.fuse_pose:
-                # pose ControlNet on its own stream from the START of the step (it only needs x, the hint features and the time
-                # embedding), its zero-convs adding into the UNet's skips / middle output in place as soon as the UNet's down path
-                # no longer reads them; host order: UNet down path, pose net, UNet up path.
-                ev_start = torch.cuda.Event()
-                ev_start.record(main)
-
-                def pose_fuse(targets, events, nread, only_mid):
-                    s_pose.wait_event(ev_start)
-                    with torch.cuda.stream(s_pose):
-                        pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose,
-                                    fuse=(targets, events, nread, only_mid))
-                    main.wait_stream(s_pose)
-                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, nread=b,
-                                only_mid_control=model.only_mid_control, emb=self.emb_cur_unet, pose_fuse=pose_fuse)
-            else:
-                s_pose.wait_stream(main)
-                with torch.cuda.stream(s_pose):
-                    pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
-                unet._pose_ready = s_pose
-                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                                only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
-                main.wait_stream(s_pose)
-            unet._bank_events, unet._pose_ready = None, None
-            if not self.table_mode:
-                main.wait_stream(s_app)   # join (the appearance stream ends at its last bank write, already consumed)
-            eps_c, eps_u = eps[:b], eps[b:]
-        elif self.overlap == 0:
-            banks = self.bank_cur_kv if self.table_mode else \
-                app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
-            pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
-            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                            only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
-            eps_c, eps_u = eps[:b], eps[b:]
+        ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
+                        self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
+        banks = self.bank_cur_kv
+        if self.merge_pose:
+            # the pose ControlNet rides in the UNet encoder's launches (second parameter set): no stream of its own
+            eps = unet.unet_pose(pose_e, self.x, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
+                                 self.emb_cur_pose, banks=banks, nread=b, only_mid_control=model.only_mid_control)
         else:
-            s_app, s_pose, s_uc = self.side
-            eps_u = None
-            if self.table_mode:
-                banks = self.bank_cur_kv
-            else:
-                s_app.wait_stream(main)
-                with torch.cuda.stream(s_app):
-                    banks = app.appearance(self.ref, self.t_cur[:self.ref.shape[0]], self.kv_app)
+            # the ControlNet's own launches on a forked stream, joined before the UNet's first pose residual add (its middle block)
+            s_pose = self.pose_stream
             s_pose.wait_stream(main)
             with torch.cuda.stream(s_pose):
-                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose)
-            if self.overlap == 2:
-                s_uc.wait_stream(main)
-                with torch.cuda.stream(s_uc):
-                    unet.ws_slot = 1
-                    eps_u = unet.unet(self.x, self.t_cur[:b], self.kv_unet_uc, nread=0)
-                    unet.ws_slot = 0
-            if not self.table_mode:
-                main.wait_stream(s_app)
+                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
+            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                            only_mid_control=model.only_mid_control, emb=self.emb_cur_unet, pose_ready=s_pose)
             main.wait_stream(s_pose)
-            if self.overlap == 2:
-                eps_c = unet.unet(self.x, self.t_cur[:b], self.kv_unet_uc, banks=banks, pose=pose, nread=b,
-                                  only_mid_control=model.only_mid_control)
-                main.wait_stream(s_uc)
-            else:
-                eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
-                                only_mid_control=model.only_mid_control)
-                eps_c, eps_u = eps[:b], eps[b:]
+        eps_c, eps_u = eps[:b], eps[b:]
         ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
         ops.counter_add(self.counter, 1)
 

@@ -243,8 +243,6 @@ class NetEngine:
         self._hint_cache = None
         self._bank_out = None
         self._bank_blocks = None
-        self._bank_events = None   # per-bank-entry events when appearance and UNet run on concurrent streams
-        self._pose_ready = None    # (stream to wait on) before the first pose residual is consumed
         self.ws_slot = 0
         self._batch2 = None        # first sample of the second parameter set while a merged (two-network) pass is running
         self._merged = None
@@ -553,8 +551,6 @@ class NetEngine:
                 dst = None if self._bank_out is None else self._bank_out[len(banks)].t
                 n1 = self.ln(t, blk["ln1"], out=dst)
                 banks.append(n1)                                                   # attention.py:287-292
-                if self._bank_events is not None:  # let a concurrent UNet stream consume this entry right away
-                    self._bank_events[len(banks) - 1].record(torch.cuda.current_stream())
                 if len(banks) == self._write_stop_at:
                     return None  # last bank entry written: the appearance net has no other output (cldm.py:497)
             else:
@@ -583,8 +579,6 @@ class NetEngine:
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
-                if self._bank_events is not None:
-                    torch.cuda.current_stream().wait_event(self._bank_events[bank_idx])
                 bb, nb = bank.b, bank.hw
                 ldvb = kv_ld(nb)
                 if isinstance(bank, BankKV):
@@ -704,31 +698,13 @@ class NetEngine:
                 break  # nothing after the last bank write influences any output (the net returns [])
         return banks
 
-    def pose(self, x, hint_feat, t_dev, ctx_kv, emb=None, fuse=None):
+    def pose(self, x, hint_feat, t_dev, ctx_kv, emb=None):
         """ControlNet.forward (cldm.py:736-757): 13 zero-conv outputs as Acts.  ``emb``: precomputed time_embedding output
         (fp32 [1 or B, emb_total]; the fused step picks it from a per-schedule table instead of running the MLP every step)."""
         assert self.kind == "pose"
         if emb is None:
             emb = self.time_embedding(t_dev, x.shape[0])
         outs, ctx_idx = [], [0]
-
-        def zero_conv(i, h, z):
-            """zero-conv i (cldm.py:733-734, 664, 689, 730).  Fused form: its epilogue adds the UNet tensor the
-            residual belongs to -- skip i of the input path, or the middle-block output -- and writes the sum IN PLACE, so that
-            ``hs.pop() + pose.pop()`` / ``h += pose.pop()`` (cldm.py:93-95,102-104) are no launches of their own.  The UNet tensor
-            may be overwritten only once every reader on the UNet's down path is done with it: the event of the FOLLOWING block."""
-            if fuse is None:
-                outs.append(self.conv(h, z["w"], h.c, k=1, bias=z["b"]))
-                return
-            targets, events, nread, only_mid = fuse
-            if only_mid and i < len(targets) - 1:
-                return                                           # cldm.py:98-100: only the middle residual is used
-            tgt = targets[i].head(nread)
-            assert tgt.b == h.b and tgt.hw == h.hw and tgt.c == h.c
-            torch.cuda.current_stream().wait_event(events[i])
-            self.conv(h, z["w"], h.c, k=1, bias=z["b"], res=tgt, out=tgt.t, lo=tgt.lo if tgt.lo is not None else False,
-                      stats=tgt.part if tgt.part is not None else False)
-
         h = self.stem_input(x)
         for i, blk in enumerate(self.input_blocks):
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
@@ -736,16 +712,17 @@ class NetEngine:
                 n = h.b * h.hw * h.c
                 ops.add_f16(h.t, hint_feat.t, h.t, n, hint_feat.b * hint_feat.hw * hint_feat.c)  # h += guided_hint
                 h.part = None   # (the producer's partial statistics no longer describe h)
-            zero_conv(i, h, self.zero_convs[i])
+            outs.append(self.conv(h, self.zero_convs[i]["w"], h.c, k=1, bias=self.zero_convs[i]["b"]))   # cldm.py:733-734
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
-        zero_conv(len(self.input_blocks), h, self.mid_out)
+        outs.append(self.conv(h, self.mid_out["w"], h.c, k=1, bias=self.mid_out["b"]))
         return outs
 
     def unet(self, x, t_dev, ctx_kv, banks=None, pose=None, nread=0, only_mid_control=False, eps_out=None, emb=None,
-             pose_fuse=None):
+             pose_ready=None):
         """ControlledUnetModelAttnPose.forward (cldm.py:59-112) on a batch whose first ``nread`` samples take the
         'read' branch (:86-107: bank attention + pose residuals) and whose remaining samples take the 'uc' branch
         (:70-84: plain UNet) -- both branches share every weight, so they run as one batch.
+        ``pose_ready``: the stream the pose residuals are being computed on (waited for before their first use).
         Returns eps as NHWC fp32 [B, H*W, 4]."""
         assert self.kind == "unet"
         b = sum(int(xi.shape[0]) for xi in x) if isinstance(x, (list, tuple)) else x.shape[0]
@@ -757,25 +734,12 @@ class NetEngine:
         hs, ctx_idx, bank_idx = [], [0], [0]
         pose = None if pose is None else list(pose)
         h = self.stem_input(x)
-        evs = [] if pose_fuse is not None else None
         for blk in self.input_blocks:
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
             hs.append(h)
-            if evs is not None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                evs.append(ev)
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
-        if pose_fuse is not None:
-            # ``pose_fuse(targets, events, nread, only_mid_control)`` runs the pose ControlNet (on its own stream) with the residual
-            # adds fused into its zero-convs: target i = skip i (may be overwritten once input block i + 1 -- the middle block for the
-            # last skip -- is done), target 12 = the middle-block output; it returns after joining that stream into this one.
-            ev_mid = torch.cuda.Event()
-            ev_mid.record(torch.cuda.current_stream())
-            pose_fuse(hs + [h], evs[1:] + [ev_mid, ev_mid], nread, only_mid_control or not use_bank)
-            pose = None
-        if self._pose_ready is not None:
-            torch.cuda.current_stream().wait_stream(self._pose_ready)
+        if pose_ready is not None:
+            torch.cuda.current_stream().wait_stream(pose_ready)
         if nread > 0 and pose is not None:
             pr = pose.pop()                                                        # cldm.py:93-95
             hh = h.head(nread)

@@ -20,8 +20,11 @@ from .ddim import DDIMSampler_ReferenceOnly, FusedStepRunner
 
 
 class FrameShardedSampler:
-    def __init__(self, model, rank=0, world=1, group=None):
+    def __init__(self, model, rank=0, world=1, group=None, force_sharded=False):
+        """``force_sharded``: run the sharded form (blocked table layout, RCCL all-gathers of the table chunks and of the results)
+        even when ``world`` is 1 -- a 1-rank process group exercises every collective of the multi-GPU path on one GPU."""
         self.model, self.rank, self.world, self.group = model, rank, world, group
+        self.sharded = world > 1 or force_sharded
 
     @staticmethod
     def frame_block(F, rank, world):
@@ -66,7 +69,7 @@ class FrameShardedSampler:
         (rank order) when ``gather`` else this rank's.  Equal frame counts per rank (use sample_sequence otherwise)."""
         model = self.model
         c, uc = self._cond(pose, ctx, ref)
-        if self.world == 1:
+        if not self.sharded:
             z, _ = model.sample_log(cond=c, batch_size=pose.shape[0], ddim=True, ddim_steps=ddim_steps, eta=0.0,
                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc, inpaint=None,
                                     x_T=x_T)
@@ -77,8 +80,8 @@ class FrameShardedSampler:
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            st.prepare(c, x_T, sampler, scale, table_mode=True, world=self.world)
-            st.run_steps(self.rank, self.world, self.group)
+            st.prepare(c, x_T, sampler, scale, table_mode=True, world=self.world, sharded=self.sharded)
+            st.run_steps(self.rank, self.world, self.group, sharded=self.sharded)
             z = st.x.clone()
             if decode:
                 z = model.decode_first_stage(z)
@@ -109,21 +112,22 @@ class FrameShardedSampler:
             if F == 0:   # empty shard: fill this rank's table blocks (collectives included), no steps
                 dummy = torch.zeros((1, 3, 8 * x_T.shape[2], 8 * x_T.shape[3]), dtype=x_T.dtype, device=x_T.device)
                 c, _ = self._cond(dummy, ctx, ref)
-                st.prepare(c, x_T[:1].contiguous(), sampler, scale, table_mode=True, world=self.world)
-                st.run_steps(self.rank, self.world, self.group, steps=False)
+                st.prepare(c, x_T[:1].contiguous(), sampler, scale, table_mode=True, world=self.world, sharded=self.sharded)
+                st.run_steps(self.rank, self.world, self.group, steps=False, sharded=self.sharded)
             for f0 in range(0, F, frames_per_batch):
                 pose = pose_frames[f0:f0 + frames_per_batch].contiguous()
                 b = pose.shape[0]
                 c, _ = self._cond(pose, ctx, ref)
-                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True, world=self.world)
-                st.run_steps(self.rank, self.world, self.group, fill=(f0 == 0))
+                st.prepare(c, x_T.expand(b, *x_T.shape[1:]).contiguous(), sampler, scale, table_mode=True, world=self.world,
+                           sharded=self.sharded)
+                st.run_steps(self.rank, self.world, self.group, fill=(f0 == 0), sharded=self.sharded)
                 outs.append(model.decode_first_stage(st.x) if decode else st.x.clone())
             if outs:
                 z = torch.cat(outs, 0)
             else:
                 side = 8 * x_T.shape[2] if decode else x_T.shape[2]
                 z = torch.zeros((0, 3 if decode else x_T.shape[1], side, side), dtype=torch.float32, device=x_T.device)
-            if gather_counts is not None and self.world > 1:
+            if gather_counts is not None and self.sharded:
                 z = self._gather(z, list(gather_counts))
         caller.wait_stream(st.stream)
         return z
@@ -217,7 +221,7 @@ class FrameShardedSampler:
         st = model._fused
         if st is None:
             st = model._fused = FusedStepRunner(model)
-        table = os.environ.get("MD_BANK_MODE", "table") != "inline"
+        table = True
 
         def timed(fn):
             ops.prof_enable(True)

@@ -267,11 +267,13 @@ def test_igemm_groupnorm_partials_rejected(dev):
     part = torch.zeros((2, 2, 64), dtype=F32, device=dev)
     with pytest.raises(_lib.MagicDanceHipError):   # 100 tokens: not a multiple of 64
         ops.igemm(x, w, 64, batch=1, hin=1, win=100, hout=1, wout=100, c0=64, out=torch.empty_like(x), gn_part=part)
-    x = torch.zeros((1, 128, 64), dtype=F16, device=dev)
+    x = torch.zeros((1, 128, 512), dtype=F16, device=dev)
+    w5 = torch.zeros((64, 512), dtype=F16, device=dev)
     ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
-    with pytest.raises(_lib.MagicDanceHipError):   # forced split-K
-        ops.igemm(x, w, 64, batch=1, hin=1, win=128, hout=1, wout=128, c0=64, out=torch.empty_like(x), gn_part=part, ws=ws,
-                  force_splitk=2)
+    with pytest.raises(_lib.MagicDanceHipError):   # forced split-K (8 k-tiles: a 2-way split is otherwise legal)
+        ops.igemm(x, w5, 64, batch=1, hin=1, win=128, hout=1, wout=128, c0=512, out=torch.empty((1, 128, 64), dtype=F16, device=dev),
+                  gn_part=part, ws=ws, force_splitk=2)
+    x = torch.zeros((1, 128, 64), dtype=F16, device=dev)
     with pytest.raises(_lib.MagicDanceHipError):   # fp32 output
         ops.igemm(x, w, 64, batch=1, hin=1, win=128, hout=1, wout=128, c0=64, out=torch.empty((1, 128, 64), dtype=F32, device=dev),
                   out_f32=True, gn_part=part)

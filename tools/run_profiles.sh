@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profiles of the headline bench (GPU box only):  bash tools/run_profiles.sh <out dir under gpurun_out>
 # 1. rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1` (configs[1])
-# 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) on a shortened run (--ddim-steps 4), never combined with traces
+# 2./3. separate PMC passes (FETCH_SIZE, WRITE_SIZE) on ONE un-captured batch of the same workload, never combined with traces
 # Summaries for profiles/ are produced afterwards by tools/summarize_profiles.py <dir> profiles/roundN
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -10,8 +10,10 @@ mkdir -p "$D"
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
 B="--no-cpu-baseline --no-roofline"
-timeout 400 rocprofv3 --kernel-trace --stats -d "$D" -o kt --output-format csv -- python bench.py --steps 2 --warmup 1 $B > "$D/bench_kt.log" 2>&1; echo kt rc=$?
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$D" -o pmc_fetch --output-format csv -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 $B > "$D/bench_pmc_fetch.log" 2>&1; echo fetch rc=$?
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$D" -o pmc_write --output-format csv -- python bench.py --steps 1 --warmup 0 --ddim-steps 4 $B > "$D/bench_pmc_write.log" 2>&1; echo write rc=$?
+timeout 400 rocprofv3 --kernel-trace --stats -d "$D" -o kt --output-format csv -- python bench.py --steps 2 --warmup 1 --no-extra $B > "$D/bench_kt.log" 2>&1; echo kt rc=$?
+# the PMC passes run the benchmarked batch itself (table pass + 50 steps + decode, the default merged pass) with every launch
+# un-captured (--no-graph): same launches, same arguments; the counter tool does not survive replays of the linear step graph
+timeout 900 rocprofv3 --pmc FETCH_SIZE -d "$D" -o pmc_fetch --output-format csv -- python bench.py --steps 1 --warmup 0 --no-graph --no-extra $B > "$D/bench_pmc_fetch.log" 2>&1; echo fetch rc=$?
+timeout 900 rocprofv3 --pmc WRITE_SIZE -d "$D" -o pmc_write --output-format csv -- python bench.py --steps 1 --warmup 0 --no-graph --no-extra $B > "$D/bench_pmc_write.log" 2>&1; echo write rc=$?
 rm -f "$D"/kt_kernel_trace.csv   # per-launch trace: too large to merge back; the stats CSV carries what profiles/ needs
 ls -la "$D"

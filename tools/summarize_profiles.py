@@ -52,7 +52,7 @@ for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         a[1] += float(r["Counter_Value"])
     ig = {k: v for k, v in agg.items() if k.startswith("igemm_kernel")}
     n = sum(v[0] for v in ig.values())
-    kb = sum(v[1] for v in ig.values())
+    kb = sum(v[1] for v in ig.values()) + sum(v[1] for k, v in agg.items() if k.startswith("igemm_splitk_reduce"))
     out[f"igemm_{key}_KB_per_launch_raw"] = kb / max(n, 1)
     out[f"igemm_{key}_launches"] = n
     lines = [f"# rocprofv3 --pmc {key} : python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extra (the benchmarked 50-step batch: table pass + graph warm-up/capture + 50 steps + decode); raw counter (KB) per kernel",
@@ -64,6 +64,9 @@ if "igemm_FETCH_SIZE_KB_per_launch_raw" in out and "igemm_WRITE_SIZE_KB_per_laun
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 -> double it;
     # WRITE_SIZE is used as reported (uncalibrated).  Units: KB.
     out["igemm_hbm_bytes_per_launch"] = (2.0 * out["igemm_FETCH_SIZE_KB_per_launch_raw"] + out["igemm_WRITE_SIZE_KB_per_launch_raw"]) * 1024.0
-    out["note"] = "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB per igemm launch, averaged over all igemm launches of the run"
+    out["igemm_launches_per_batch"] = out["igemm_FETCH_SIZE_launches"]
+    out["note"] = ("traffic = (2*FETCH_SIZE + WRITE_SIZE) KB per igemm launch (split-K reduce launches included in the byte sum, counted "
+                   "under their GEMM), averaged over all igemm launches of ONE benchmarked batch (bench.py --steps 1 --warmup 0 "
+                   "--no-graph: reference-KV table pass + 50 DDIM steps + first-stage decode, the default merged pass, un-captured)")
 json.dump(out, open(dst + "_pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

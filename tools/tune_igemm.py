@@ -50,6 +50,8 @@ if os.environ.get("TUNE_ONLY_NEW"):   # keep the committed table, time only the 
     shapes = {k: v for k, v in shapes.items() if k[:6] not in have}
 if os.environ.get("TUNE_FILTER") == "shortk":   # K <= 640 at big M: candidates with 2 / 4 k-tiles per stage were not tried there before
     shapes = {k: v for k, v in shapes.items() if k[2] <= 640 and k[0] > 16384}
+if os.environ.get("TUNE_FILTER") == "smallm":   # the 32x32 / 16x16 / 8x8 levels of a one-frame step: where k-groups / split-K matter
+    shapes = {k: v for k, v in shapes.items() if k[0] <= 4096}
 if os.environ.get("TUNE_FILTER") == "linear":   # 1x1 convs / linears only (their time is mostly epilogue: re-tune after epilogue changes)
     shapes = {k: v for k, v in shapes.items() if k[3] == 1}
 print(f"{len(shapes)} unique igemm shapes", flush=True)
@@ -84,18 +86,23 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
         if M <= 4096 or K <= 640:
             cfgs += [32] + ([33] if (N % 80 == 0 and act != 2) else [])       # four
     ln_shape = ks == 1 and c1 == 0 and K in (320, 640, 1280) and N in (K, 3 * K, 8 * K)   # possibly a folded-LayerNorm GEMM
-    if buf_ok and not ln_shape and M >= 2048:
-        cfgs += [34, 36] + ([35, 37] if N % 160 == 0 or N >= 640 else [])   # 32x32x16-fragment tiles
-    if buf_ok and os.environ.get("TUNE_DEEP"):
-        cfgs += list(range(16, 24))  # counted-vmcnt 3..6-stage pipelines (exploration only, see igemm.hip)
     nk = (K + 63) // 64
     splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16, 24) if act != 2 and M <= 4096 and nk // s >= 2 and s * M * N * 4 <= ws.numel()]
-    res = []
+    # k-groups per workgroup (max_kg() in igemm.hip): in-workgroup split-K, no slabs / reduce launch
+    MAX_KG = {12: 2, 13: 2, 14: 2, 15: 4, 24: 2, 25: 2, 26: 2, 27: 4, 28: 2, 29: 2}
+    cands = []
     for cfg in cfgs:
         for sp in splits:
+            cands.append((cfg, sp, 1))
+            for kg in (2, 4):
+                if kg <= MAX_KG.get(cfg, 1) and M <= 16384 and nk >= 2 * kg and sp in (1, 2, 3, 4, 6, 8) and nk // (sp * kg) >= 1:
+                    cands.append((cfg, sp, kg))
+    res = []
+    for cfg, sp, kg in cands:
+        if True:
             def run(i=0):
                 ops.igemm(x0, wts[i % ncopy], N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
-                          bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp)
+                          bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp, force_kg=kg)
             try:
                 with torch.cuda.stream(side):
                     run()
@@ -114,9 +121,9 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
                     side.synchronize()
                     us = e0.elapsed_time(e1) / REPS * 1e3
                     g.destroy()
-                res.append((us, cfg, sp))
+                res.append((us, cfg, sp, kg))
             except Exception as ex:  # noqa: BLE001
-                print("ERR", key, cfg, sp, ex, flush=True)
+                print("ERR", key, cfg, sp, kg, ex, flush=True)
     res.sort()
     # split-K costs a second launch slot and slab traffic that the isolated timing under-prices when three network streams
     # share the GPU: take a split config only when it beats the best unsplit one by > SPLIT_MARGIN
@@ -124,11 +131,12 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     if best_unsplit is not None and res[0][2] > 1 and res[0][0] > (1.0 - SPLIT_MARGIN) * best_unsplit[0]:
         res.remove(best_unsplit)
         res.insert(0, best_unsplit)
-    us, cfg, sp = res[0]
+    us, cfg, sp, kg = res[0]
     total_best += us * count
-    lines.append(f"    {{{M}, {N}, {K}, {ks}, {st}, {up}, {cfg}, {sp}}},  // x{count} {us:.1f}us {2.0 * M * N * K / us / 1e6:.0f}TF (B={B} {h}x{w} c={c0}+{c1})")
-    print(lines[-1], "| runner-ups:", " ".join(f"c{c}/s{s}:{u:.1f}" for u, c, s in res[1:4]), flush=True)
+    lines.append(f"    {{{M}, {N}, {K}, {ks}, {st}, {up}, {cfg}, {sp}, {kg}}},  // x{count} {us:.1f}us {2.0 * M * N * K / us / 1e6:.0f}TF (B={B} {h}x{w} c={c0}+{c1})")
+    print(lines[-1], "| runner-ups:", " ".join(f"c{c}/s{s}/g{g_}:{u:.1f}" for u, c, s, g_ in res[1:5]),
+          "| best kg=1:", " ".join(f"c{c}/s{s}:{u:.1f}" for u, c, s, g_ in [r for r in res if r[3] == 1][:1]), flush=True)
 with open(out_path, "w") as f:
-    f.write("// generated by tools/tune_igemm.py on an MI355X: {M, N, K, ksize, stride, ups, cfg, split},\n")
+    f.write("// generated by tools/tune_igemm.py on an MI355X: {M, N, K, ksize, stride, ups, cfg, split, k-groups},\n")
     f.write("\n".join(lines) + "\n")
 print(f"sum over one step of best times: {total_best / 1e3:.3f} ms", flush=True)

@@ -61,8 +61,10 @@ class DDIMSampler_ReferenceOnly(object):
     def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
                quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
                corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
-               unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, inpaint=None, **kwargs):
-        """ddim.py:391-458."""
+               unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, inpaint=None, force_generic=False,
+               **kwargs):
+        """ddim.py:391-458.  ``force_generic`` (not in the reference): take the per-call route -- one apply_model per branch per
+        step, exactly the reference's call structure -- even where the fused table + graph route applies (tests compare the two)."""
         if inpaint is not None or mask is not None or score_corrector is not None or quantize_x0 or dynamic_threshold:
             raise NotImplementedError("inpaint / mask / score-corrector variants are outside the pose hot path")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
@@ -71,7 +73,8 @@ class DDIMSampler_ReferenceOnly(object):
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, x_T=x_T,
                                   log_every_t=log_every_t, temperature=temperature, noise_dropout=noise_dropout,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
-                                  unconditional_conditioning=unconditional_conditioning, ucg_schedule=ucg_schedule)
+                                  unconditional_conditioning=unconditional_conditioning, ucg_schedule=ucg_schedule,
+                                  force_generic=force_generic)
 
     # ------------------------------------------------------------------ loop (ddim.py:461-516)
     @torch.no_grad()
@@ -89,7 +92,7 @@ class DDIMSampler_ReferenceOnly(object):
         if (not force_generic and ucg_schedule is None and noise_dropout == 0.
                 and self._fused_ok(cond, unconditional_conditioning, unconditional_guidance_scale)):
             return self._fused_sampling(cond, img, unconditional_guidance_scale, callback, img_callback, log_every_t,
-                                        intermediates)
+                                        intermediates, unconditional_conditioning)
 
         for i, step in enumerate(time_range):
             index = total_steps - i - 1
@@ -176,17 +179,23 @@ class DDIMSampler_ReferenceOnly(object):
 
     # ------------------------------------------------------------------ fused route
     def _fused_ok(self, c, uc, scale):
-        if uc is None or scale == 1. or not isinstance(c, dict) or not getattr(self.model, "has_pose", True):
+        """The fused (table + captured graph) route covers eta = 0 sampling of: the entry points' default -- "controlnet is more
+        important" CFG (:595-605) with ``wonoise`` --, the "balance" CFG branch (:540-567: the unconditional dict carries the
+        reference too), the noisy reference (``wonoise`` False, :529-535) and the stage-1 model without pose ControlNet.  Everything
+        else (overlap_sampling windows, eta > 0, a void text context, guidance scale 1) takes the generic per-call route."""
+        if uc is None or scale == 1. or not isinstance(c, dict) or not isinstance(uc, dict):
             return False
-        if uc.get("image_control") is not None or c.get("overlap_sampling"):
+        if c.get("overlap_sampling") or c.get("image_control") is None or c.get("c_crossattn_void") is not None:
             return False
-        if c.get("image_control") is None or c.get("c_concat") is None or not c.get("wonoise"):
+        if getattr(self.model, "has_pose", True) and c.get("c_concat") is None:
             return False
-        if c.get("c_crossattn_void") is not None:
-            return False
+        if uc.get("image_control") is not None:   # balance: both halves of the 2B batch are conditional passes
+            for k in c:
+                if isinstance(c[k], list) and (k not in uc or len(uc[k]) != len(c[k])):
+                    return False
         return float(np.abs(self.ddim_sigmas).max()) == 0.0
 
-    def _fused_sampling(self, c, img, scale, callback, img_callback, log_every_t, intermediates):
+    def _fused_sampling(self, c, img, scale, callback, img_callback, log_every_t, intermediates, uc=None):
         model = self.model
         st = model._fused
         if st is None:
@@ -196,7 +205,7 @@ class DDIMSampler_ReferenceOnly(object):
         caller = torch.cuda.current_stream()
         st.stream.wait_stream(caller)
         with torch.cuda.stream(st.stream):
-            st.prepare(c, img, self, scale, table_mode=True)
+            st.prepare(c, img, self, scale, table_mode=True, uc=uc)
 
             def on_step(i):
                 index = total - i - 1
@@ -242,6 +251,15 @@ class FusedStepRunner:
         self.table_chunks = 2     # sharded: all-gathers per table (the 2nd overlaps the loop)
         self.tkey = None
         self.pose_stream = torch.cuda.Stream(device=model.device)
+        # HBM -> Infinity Cache weight prefetch (md_prefetch): a step streams 2.4 GB of weights through the MI355X's 256 MB
+        # memory-side cache, so every layer meets its weights cold.  The step's weight stream (recorded once, in launch order) is cut
+        # into groups of ~prefetch_group bytes; when the step reaches group g, a forked stream pulls group g + 1 in (the last group
+        # pulls group 0 of the next step): the small, latency-bound GEMMs of a one-frame step then wait for the Infinity Cache instead
+        # of HBM in every k-loop iteration.  MD_PREFETCH=0 disables (tests check on == off bit for bit).
+        self.prefetch = os.environ.get("MD_PREFETCH", "1") != "0"
+        self.prefetch_group = 40 << 20
+        self.pf_stream = torch.cuda.Stream(device=model.device)
+        self._pf_groups = None     # [(first md_igemm launch index of the group, device range table, n ranges, bytes)]
 
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
@@ -260,52 +278,91 @@ class FusedStepRunner:
         nblocks = -(-(-(-S // per)) // world) * world
         return per, nblocks
 
-    def prepare(self, c, x_T, sampler, scale, table_mode=False, world=1, sharded=None):
-        """Per-batch buffers (x, pose features, schedule tables; keyed on the batch geometry) and -- in table mode -- the
-        reference-KV table (keyed on the reference / schedule geometry only, so a sequence sampled in batches of different
-        sizes keeps one table)."""
+    def prepare(self, c, x_T, sampler, scale, table_mode=True, world=1, sharded=None, uc=None):
+        """Per-batch buffers (x, pose features, schedule tables; keyed on the batch geometry) and the reference-KV table (keyed on
+        the reference / schedule geometry only, so a sequence sampled in batches of different sizes keeps one table).
+
+        The step's UNet batch is always 2b samples [x, x].  Forms (``uc``: the unconditional dict, None = the default form):
+          default  first half cond (text c, bank, pose residuals), second half uncond (text c, neither)   ddim.py:595-605
+          balance  first half text uc, second half text c; BOTH halves read the bank and take pose residuals  ddim.py:540-567
+                   (appearance net / ControlNet see the same 2b-sample batch, so the bank is per sample: bref = 2b)
+          noisy    default, but the appearance net sees q_sample(reference, t) with fresh noise per step and frame (:529-535): the
+                   table rows are computed from per-step noisy references drawn HERE, in step order (bref = b)
+          stage 1  no pose ControlNet (ControlLDMReferenceOnly)"""
+        assert table_mode, "the fused route always runs from the reference-KV table"
         model, dev = self.model, self.model.device
         app, pose_e, unet = model.engines()
         b, cch, hh, ww = x_T.shape
+        balance = uc is not None and uc.get("image_control") is not None
+        noisy = not c.get("wonoise", True)
+        has_pose = pose_e is not None
         ref = torch.cat(c["image_control"], 1).detach().to(device=dev, dtype=F32)
-        if ref.shape[0] > 1 and self._same_rows(ref):
-            ref = ref[:1]          # every frame shares the reference latent: one appearance pass, bank broadcast
-        ref = ref.contiguous()
         ctx = torch.cat(c["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
-        if ctx.shape[0] > 1 and self._same_rows(ctx):
-            ctx = ctx[:1]
-        ctx_app = ctx if ctx.shape[0] in (1, ref.shape[0]) else ctx[:ref.shape[0]]
-        ctx_unet = ctx if ctx.shape[0] == 1 else torch.cat([ctx, ctx], 0)
-        hint = torch.cat(c["c_concat"], 1)
+        rep = lambda t, n: t if t.shape[0] == n else t.expand(n, *t.shape[1:])  # noqa: E731
+        if balance:
+            ctx_u = torch.cat(uc["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
+            base = rep(ref, b)     # (:529-551: both halves see the CONDITIONAL dict's reference; uc's only switches the branch)
+            ref = torch.cat([base, base], 0)                                     # x_in / ref_in = [uc half, c half]
+            ctx = torch.cat([rep(ctx_u, b), rep(ctx, b)], 0)
+            ctx_app = ctx_unet = ctx
+            nread, n_pose = 2 * b, (2 * b if has_pose else 0)
+        else:
+            if noisy:
+                ref = base = rep(ref, b)      # per-frame noise: one bank per frame
+            elif ref.shape[0] > 1 and self._same_rows(ref):
+                ref = ref[:1]          # every frame shares the reference latent: one appearance pass, bank broadcast
+            if ctx.shape[0] > 1 and self._same_rows(ctx):
+                ctx = ctx[:1]
+            ctx_app = ctx if ctx.shape[0] in (1, ref.shape[0]) else ctx[:ref.shape[0]]
+            ctx_unet = ctx if ctx.shape[0] == 1 else torch.cat([ctx, ctx], 0)
+            nread, n_pose = b, (b if has_pose else 0)
+        ref = ref.contiguous()
+        bref = ref.shape[0]
+        self.balance, self.nread, self.n_pose = balance, nread, n_pose
+        if has_pose:
+            hint = torch.cat(c["c_concat"], 1)
+            if balance:
+                hint = torch.cat([rep(torch.cat(uc["c_concat"], 1), b), rep(hint, b)], 0)
+        else:
+            hint = torch.zeros((0,), device=dev)
         S = sampler.ddim_timesteps.shape[0]
+        # appearance passes batch ``per_pass`` timesteps x bref references: a per-sample text context repeats with the references
+        per_pass = max(1, self.bank_chunk // bref)
+        if ctx_app.shape[0] > 1:
+            ctx_app = ctx_app.repeat(per_pass, 1, 1)
         # the context K/V caches are keyed on the tensor passed in; keep stable tensors across calls
-        if getattr(self, "_ctx_src", None) is None or not (self._ctx_src.shape == ctx.shape and torch.equal(self._ctx_src, ctx)):
-            self._ctx_src = ctx.clone()
+        ckey = torch.cat([ctx_unet.reshape(-1), ctx_app.reshape(-1)[:1]])
+        if getattr(self, "_ctx_src", None) is None or not (self._ctx_src.shape == ckey.shape and torch.equal(self._ctx_src, ckey)
+                                                          and self._ctx_app.shape == ctx_app.shape):
+            self._ctx_src = ckey.clone()
             self._ctx_app, self._ctx_unet = ctx_app.contiguous().clone(), ctx_unet.contiguous().clone()
+            self._ctx_pose = (self._ctx_unet if balance else (ctx if ctx.shape[0] in (1, b) else ctx[:b])).contiguous().clone()
         self.kv_app = app.context_kv(self._ctx_app)
-        self.kv_pose = pose_e.context_kv(self._ctx_app if self._ctx_app.shape[0] in (1, b) else self._ctx_src)
         self.kv_unet = unet.context_kv(self._ctx_unet)
-        self.kv_merged = unet.merged_context_kv(self.kv_unet, self.kv_pose, b) if self.merge_pose else None
+        if has_pose:
+            self.kv_pose = pose_e.context_kv(self._ctx_pose)
+            self.kv_merged = unet.merged_context_kv(self.kv_unet, self.kv_pose, b, n_pose) if self.merge_pose else None
+        else:
+            self.kv_pose = self.kv_merged = None
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
-        bref = ref.shape[0]
-        key = (b, cch, hh, ww, S, bref, tuple(hint.shape), bool(table_mode), self.kv_app[0][0].data_ptr(),
-               self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
+        key = (b, cch, hh, ww, S, bref, tuple(hint.shape), balance, noisy, self.kv_app[0][0].data_ptr(),
+               0 if self.kv_pose is None else self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
         if key != self.key:
-            self._allocate(key, b, cch, hh, ww, S, bref, table_mode)
-        if table_mode:
-            per, nblocks = self.plan_table(S, bref, world, sharded)
-            from . import engine as _eng
-            tkey = (cch, hh, ww, S, bref, per, nblocks, _eng.ATTN_FP8)
-            if tkey != self.tkey:
-                self._allocate_table(tkey, hh, ww, S, bref, per, nblocks)
+            self._allocate(key, b, cch, hh, ww, S, bref, True)
+        per, nblocks = self.plan_table(S, bref, world, sharded)
+        from . import engine as _eng
+        tkey = (cch, hh, ww, S, bref, per, nblocks, _eng.ATTN_FP8)
+        if tkey != self.tkey:
+            self._allocate_table(tkey, hh, ww, S, bref, per, nblocks)
         self.ref.copy_(ref)
         self.x.copy_(x_T)
-        hf = pose_e.hint_features(hint)
-        if self.hint_feat is None or self.hint_feat.t.shape != hf.t.shape:
-            self.hint_feat = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
-            self._drop_graph()
-        self.hint_feat.t.copy_(hf.t)
+        if has_pose:
+            hf = pose_e.hint_features(hint)
+            if self.hint_feat is None or self.hint_feat.t.shape != hf.t.shape:
+                self.hint_feat = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
+                self._drop_graph()
+            self.hint_feat.t.copy_(hf.t)
         # per-step tables: timestep (as float, repeated for the 2B-sample UNet batch) and DDIM coefficients
         steps = np.flip(sampler.ddim_timesteps).astype(np.float32)
         idx = np.arange(S)[::-1]
@@ -314,12 +371,19 @@ class FusedStepRunner:
         self.ts_table.copy_(torch.from_numpy(np.repeat(steps[:, None], self.ts_table.shape[1], 1).copy()))
         self.coef_table.copy_(torch.from_numpy(coef))
         self.counter.zero_()
+        # noisy reference: q_sample(reference, t) per step, the noise drawn in step order exactly as the per-step route draws it
+        # (one randn_like(reference) per step, ddpm.py:356-359 through ddim.py:529-535) -- the table rows are built from these
+        self.ref_rows = None
+        if noisy:
+            tl = torch.from_numpy(np.flip(sampler.ddim_timesteps).copy()).to(dev).long()
+            rows = [model.q_sample(base.contiguous(), tl[i].expand(b)) for i in range(S)]     # one [b, ...] draw per step
+            self.ref_rows = torch.stack([torch.cat([r, r], 0) if balance else r for r in rows]).contiguous()
         # Time-embedding tables: timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers depend on the step only, not on
         # x or the frame: computed here for all S steps at once (same kernels, rows = steps), so that a step reads ONE row per
         # network (md_select_row_f32) instead of running 4 dependent launches per network at the head of its critical path.
         # (the tables and the current-row buffers are PERSISTENT: the captured step graph holds their addresses)
         arena = unet.arena
-        for name, eng in (("unet", unet), ("pose", pose_e)):
+        for name, eng in (("unet", unet),) + ((("pose", pose_e),) if has_pose else ()):
             arena.reset()
             tab = eng.time_embedding(self.ts_table[:, 0].contiguous(), S)
             old = getattr(self, "emb_table_" + name, None)
@@ -333,6 +397,26 @@ class FusedStepRunner:
         if self.graph is not None:
             self.graph.destroy()
             self.graph = None
+        self._pf_groups = None
+
+    def _build_prefetch_groups(self, stream_of_weights):
+        """stream_of_weights: per md_igemm launch of one step, its weight ranges [(address, bytes), ...] in launch order"""
+        groups, cur, seen, cur_bytes, first = [], [], set(), 0, 0
+        for i, ws in enumerate(stream_of_weights):
+            for ptr, nbytes in ws:
+                nbytes &= ~127
+                if nbytes <= 0 or ptr in seen:
+                    continue
+                if cur and (cur_bytes + nbytes > self.prefetch_group or len(cur) == 64):
+                    groups.append((first, cur, cur_bytes))
+                    cur, seen, cur_bytes, first = [], set(), 0, i
+                seen.add(ptr)
+                cur.append((ptr, nbytes))
+                cur_bytes += nbytes
+        if cur:
+            groups.append((first, cur, cur_bytes))
+        dev = self.model.device
+        self._pf_groups = [(fi, torch.tensor(rs, dtype=torch.int64, device=dev), len(rs), nb) for fi, rs, nb in groups]
 
     def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
         dev = self.model.device
@@ -425,8 +509,12 @@ class FusedStepRunner:
                 tmp = [Act(t[:nb], nb, 1, t.shape[1], t.shape[2]) for t in self._bank_tmp[1]]
                 app.arena.reset()
                 t_dev = self.ts_table[r0:r0 + tc, 0].repeat_interleave(bref).contiguous()
-                x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
-                app.appearance(x, t_dev, self.kv_app, bank_out=tmp)
+                if self.ref_rows is not None:
+                    x = self.ref_rows[r0:r0 + tc].reshape(nb, *self.ref.shape[1:])
+                else:
+                    x = self.ref.repeat(tc, 1, 1, 1) if tc > 1 else self.ref
+                kv = self.kv_app if self.kv_app[0][2] in (1, nb) else [(k[:nb], vt[:nb], nb, tk, ldv) for (k, vt, _, tk, ldv) in self.kv_app]
+                app.appearance(x, t_dev, kv, bank_out=tmp)
                 for e in range(len(self.bank_geo)):
                     k_out, vt_out = self._row_views(e, r0, tc)
                     unet.project_bank(e, tmp[e], k_out, vt_out)
@@ -498,30 +586,69 @@ class FusedStepRunner:
         ops.select_row_f32(self.ts_table, self.counter, 0, self.t_cur, 2 * b, self.S)
         ops.select_row_f32(self.coef_table, self.counter, 0, self.coef_cur, 5, self.S)
         ops.select_row_f32(self.emb_table_unet, self.counter, 0, self.emb_cur_unet, self.emb_cur_unet.shape[1], self.S)
-        ops.select_row_f32(self.emb_table_pose, self.counter, 0, self.emb_cur_pose, self.emb_cur_pose.shape[1], self.S)
+        if pose_e is not None:
+            ops.select_row_f32(self.emb_table_pose, self.counter, 0, self.emb_cur_pose, self.emb_cur_pose.shape[1], self.S)
         arena = unet.arena
         arena.reset()
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
+        pf = self.prefetch and (self.merge_pose or pose_e is None)
+        recorded, state = [], [0, 0]   # (launch index, next group)
+
+        def weight_hook(ws):
+            if self._pf_groups is None:
+                recorded.append(ws)
+                return
+            g = self._pf_groups
+            if state[1] < len(g) and state[0] == g[state[1]][0]:
+                # the step is entering group ``state[1]``: pull the NEXT group's weights (after the last group: the first group of
+                # the next step) into the Infinity Cache on the forked stream
+                nxt = g[(state[1] + 1) % len(g)]
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self.pf_stream.wait_event(ev)
+                with torch.cuda.stream(self.pf_stream):
+                    ops.prefetch(nxt[1], nxt[2], nxt[3])
+                state[1] += 1
+            state[0] += 1
+        if pf:
+            ops.WEIGHT_HOOK = weight_hook
+        try:
+            eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
+        finally:
+            ops.WEIGHT_HOOK = None
+        if pf and self._pf_groups is None:
+            self._build_prefetch_groups(recorded)
+        elif pf:
+            main.wait_stream(self.pf_stream)   # join (a captured graph must end with every forked stream merged back)
+        ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
+        ops.counter_add(self.counter, 1)
+
+    def _networks(self, model, pose_e, unet, b, main):
+        """the network passes of one step: (eps_cond, eps_uncond), NHWC fp32"""
         ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
                         self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
         banks = self.bank_cur_kv
-        if self.merge_pose:
+        nread, n_pose = self.nread, self.n_pose
+        if pose_e is None:
+            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, nread=nread,
+                            only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
+        elif self.merge_pose:
             # the pose ControlNet rides in the UNet encoder's launches (second parameter set): no stream of its own
             eps = unet.unet_pose(pose_e, self.x, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
-                                 self.emb_cur_pose, banks=banks, nread=b, only_mid_control=model.only_mid_control)
+                                 self.emb_cur_pose, banks=banks, nread=nread, n_pose=n_pose, only_mid_control=model.only_mid_control)
         else:
             # the ControlNet's own launches on a forked stream, joined before the UNet's first pose residual add (its middle block)
             s_pose = self.pose_stream
             s_pose.wait_stream(main)
             with torch.cuda.stream(s_pose):
-                pose = pose_e.pose(self.x, self.hint_feat, self.t_cur[:b], self.kv_pose, emb=self.emb_cur_pose)
-            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=b,
+                pose = pose_e.pose([self.x] * (n_pose // b), self.hint_feat, self.t_cur[:n_pose], self.kv_pose, emb=self.emb_cur_pose)
+            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=nread,
                             only_mid_control=model.only_mid_control, emb=self.emb_cur_unet, pose_ready=s_pose)
             main.wait_stream(s_pose)
-        eps_c, eps_u = eps[:b], eps[b:]
-        ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
-        ops.counter_add(self.counter, 1)
+        if self.balance:
+            return eps[b:], eps[:b]      # (eps_c, eps_u): the batch is [uc half, c half] (ddim.py:566)
+        return eps[:b], eps[b:]
 
     def step(self):
         if not self.use_graph:

@@ -768,32 +768,37 @@ class NetEngine:
                             zip_params(self.middle_block, pose_e.middle_block))
         return self._merged[1], self._merged[2]
 
-    def merged_context_kv(self, ctx_kv, pose_kv, b):
+    def merged_context_kv(self, ctx_kv, pose_kv, b, n_pose=None):
         """cross-attention K / V^T of the merged encoder: per transformer block, the UNet's rows for its 2b samples followed by
-        the ControlNet's rows for its b samples (small: 77 tokens; built once per context, cached on the source buffers)"""
-        key = (ctx_kv[0][0].data_ptr(), pose_kv[0][0].data_ptr(), b)
+        the ControlNet's rows for its n_pose (b, or 2b in balance mode) samples (small: 77 tokens; built once per context, cached
+        on the source buffers)"""
+        n_pose = b if n_pose is None else n_pose
+        key = (ctx_kv[0][0].data_ptr(), pose_kv[0][0].data_ptr(), b, n_pose)
         cache = getattr(self, "_merged_kv", None)
         if cache is not None and cache[0] == key:
             return cache[1]
         out = []
         for (ku, vu, bu, tk, ldv), (kp, vp, bp, tkp, ldvp) in zip(ctx_kv, pose_kv):   # zip stops after the encoder + middle blocks
-            assert (tk, ldv) == (tkp, ldvp) and bu in (1, 2 * b) and bp in (1, b)
-            k = torch.cat([ku.expand(2 * b, -1, -1), kp.expand(b, -1, -1)], 0).contiguous()
-            vt = torch.cat([vu.expand(2 * b, -1, -1), vp.expand(b, -1, -1)], 0).contiguous()
-            out.append((k, vt, 3 * b, tk, ldv))
+            assert (tk, ldv) == (tkp, ldvp) and bu in (1, 2 * b) and bp in (1, n_pose)
+            k = torch.cat([ku.expand(2 * b, -1, -1), kp.expand(n_pose, -1, -1)], 0).contiguous()
+            vt = torch.cat([vu.expand(2 * b, -1, -1), vp.expand(n_pose, -1, -1)], 0).contiguous()
+            out.append((k, vt, 2 * b + n_pose, tk, ldv))
         self._merged_kv = (key, out, (ctx_kv, pose_kv))
         return out
 
     def unet_pose(self, pose_e, x, hint_feat, ctx_kv, ctx_kv_merged, emb, emb_pose, banks=None, nread=0, only_mid_control=False,
-                  eps_out=None):
-        """One DDIM step's UNet (cond + uncond samples, cldm.py:59-112) and pose ControlNet (cldm.py:736-757) as ONE pass: the
-        ControlNet is a copy of the UNet's input + middle blocks with its own weights and the same input x_t, so its b samples
+                  eps_out=None, n_pose=None):
+        """One DDIM step's UNet (2b samples [x, x], cldm.py:59-112) and pose ControlNet (cldm.py:736-757) as ONE pass: the
+        ControlNet is a copy of the UNet's input + middle blocks with its own weights and the same input x_t, so its samples
         ride behind the UNet's 2b in every launch of the encoder (second parameter set of md_igemm / md_groupnorm) instead of
         running ~110 small launches of their own on a concurrent stream.  What remains of the ControlNet: the guided-hint add
         after the stem (:744-747) and the 13 zero-convs (:733-734), whose epilogues add straight into the skip / middle tensors
-        of the cond samples (:93-95, 102-104) -- issued after the encoder, which must read those tensors unmodified.
-        x: fp32 latent [b, 4, H, W]; emb / emb_pose: ONE row each (all samples share the timestep)."""
-        assert self.kind == "unet" and emb.shape[0] == 1 and emb_pose.shape[0] == 1 and nread in (0, x.shape[0])
+        of the ``nread`` reading samples (:93-95, 102-104) -- issued after the encoder, which must read those tensors unmodified.
+        x: fp32 latent [b, 4, H, W]; emb / emb_pose: ONE row each (all samples share the timestep).  ``n_pose`` ControlNet samples =
+        ``nread`` reading UNet samples: b (default: the cond half reads, the uncond half does not) or 2b (balance: both halves)."""
+        b = int(x.shape[0])
+        n_pose = b if n_pose is None else n_pose
+        assert self.kind == "unet" and emb.shape[0] == 1 and emb_pose.shape[0] == 1 and nread in (0, n_pose) and n_pose in (b, 2 * b)
         b = int(x.shape[0])
         b2 = 2 * b
         use_bank_in = nread > 0 and banks is not None and len(banks) > 0
@@ -804,7 +809,7 @@ class NetEngine:
         self._batch2 = b2
         try:
             demb = Dual(emb, emb_pose)
-            h = self.stem_input([x, x, x])
+            h = self.stem_input([x] * (2 + n_pose // b))
             for i, blk in enumerate(inb):
                 h = self.run_block(blk, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
                 if i == 0:   # h += guided_hint on the ControlNet's samples

@@ -154,11 +154,13 @@ def test_frames_are_independent(dev):
         assert _rel(zf.cpu().numpy(), z[f:f + 1].cpu().numpy(), f"frame {f} alone vs in batch") <= 5e-3
 
 
+@pytest.mark.parametrize("route", ["fused", "generic"])
 @pytest.mark.parametrize("name", ["small_b1_balance", "small_b1_stage1"])
-def test_variants_match_reference_golden(dev, name):
+def test_variants_match_reference_golden(dev, name, route):
     """the 'balance' CFG branch (2B-batched pass with the reference attention on both halves, ddim.py:540-567)
-    and the stage-1 model (ControlLDMReferenceOnly + ControlledUnetModelAttn from cldm_v15_reference_only.yaml), both through
-    the generic per-step sampler route, against goldens of the unmodified reference."""
+    and the stage-1 model (ControlLDMReferenceOnly + ControlledUnetModelAttn from cldm_v15_reference_only.yaml) against goldens
+    of the unmodified reference -- through the fused route (reference-KV table + one captured HIP graph per step: per-sample bank
+    rows for balance, no ControlNet for stage 1) and through the per-call route."""
     g = H.load_golden(name)
     stage1 = name.endswith("stage1")
     model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device=dev,
@@ -172,8 +174,9 @@ def test_variants_match_reference_golden(dev, name):
     traj = []
     z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
                             unconditional_conditioning=uc, inpaint=None, x_T=x_T,
-                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
-    assert _rel(z.cpu().numpy(), g["z"], f"{name} z({int(g['steps'])} steps) vs golden") <= TOL_Z
+                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()), force_generic=(route == "generic"))
+    assert (model._fused is not None and model._fused.graph is not None) == (route == "fused")
+    assert _rel(z.cpu().numpy(), g["z"], f"{name} z({int(g['steps'])} steps) vs golden, {route} route") <= TOL_Z
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], f"{name} pred_x0 trajectory vs golden") <= TOL_Z
 
 
@@ -215,9 +218,11 @@ def test_repeated_sampling_is_bit_identical(dev):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
-def test_wonoise_false_matches_reference_golden(dev):
-    """wonoise=False (ddim.py:529-535 + ddpm.py:356-359) on the generic per-step route; the per-step q_sample draws
-    come from the fixture (tests/test_host_logic.py::noisy_q_sample), everything else runs on the HIP kernels."""
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_wonoise_false_matches_reference_golden(dev, route):
+    """wonoise=False (ddim.py:529-535 + ddpm.py:356-359) on the fused route (table rows from the per-step noisy
+    references) and on the per-call route; the per-step q_sample draws come from the fixture
+    (tests/test_host_logic.py::noisy_q_sample), everything else runs on the HIP kernels."""
     from tests.test_host_logic import noisy_q_sample
     g = H.load_golden("small_b1_noisy")
     model = _model(g, dev)
@@ -229,10 +234,10 @@ def test_wonoise_false_matches_reference_golden(dev):
         traj = []
         z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
                                 unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"].to(dev),
-                                img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
+                                img_callback=lambda p, i: traj.append(p.detach().cpu().clone()), force_generic=(route == "generic"))
     finally:
         del model.q_sample
-    assert model._fused is None
+    assert (model._fused is not None) == (route == "fused")
     assert _rel(z.cpu().numpy(), g["z"], "small_b1_noisy z vs golden") <= TOL_Z
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b1_noisy pred_x0 trajectory vs golden") <= TOL_Z
 

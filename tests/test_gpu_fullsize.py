@@ -180,29 +180,70 @@ def test_configs2_batch8_50steps_frames_match_single_frame_references(dev, model
     assert _rel(z1.cpu().numpy(), g3["z"]) <= 1.8e-3
 
 
-def test_realistic_latent_scale_absolute_deviation(dev, model):
-    """The north star's "<= 1e-3 max-abs latent deviation" in ABSOLUTE terms at a realistic latent scale.  The seeded weights
-    predict an eps that does not track the noise, so the standard case amplifies a unit-variance x_T to max|z| = 78; golden
-    c1r_b1_s50 starts the same 50-step run from x_T / 16 and ends at the scale of a real SD-1.5 latent.  fp16 MFMA operands bound
-    one eps evaluation at ~1.2e-3 of max|eps|, so the absolute bar is NOT reachable by this (or any) fp16-
-    operand pipeline: the measured absolute deviation is logged and asserted at 2x its measured value."""
+def test_small_x_T_recurrence_sensitivity(dev, model):
+    """golden c1r_b1_s50: the configs[1] run started from x_T / 16.  It still ends at max|z| = 50 -- with the seeded weights it is
+    the eps term (coefficient 1 / sqrt(a_t) = 14 at the first steps), not x_T, that drives the latent.  Measured: each single
+    evaluation is as accurate as at the standard scale, but the free-running 50-step latent deviates 4.6e-3 of max|z| instead of
+    6e-4: with a small x_t the seeded network's eps reacts more strongly to its own input, and the recurrence amplifies the
+    per-step fp16 rounding.  (A property of the dynamics, not of a kernel: the per-evaluation check below holds the kernels to the
+    usual bound.)"""
     g = _golden_or_skip("c1r_b1_s50")
     steps = int(g["steps"])
     inp = H.case_inputs(dict(g, x_T=g["x_T"] / float(g["xt_scale"])))
     mv = lambda d: {k: ([t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in d.items()}  # noqa: E731
-    x_T = torch.from_numpy(g["x_T"]).to(dev)
     z, _ = model.sample_log(cond=mv(inp["c"]), batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
-                            unconditional_conditioning=mv(inp["uc"]), inpaint=None, x_T=x_T)
+                            unconditional_conditioning=mv(inp["uc"]), inpaint=None, x_T=torch.from_numpy(g["x_T"]).to(dev))
     z = z.cpu().numpy()
     ab, zmax = float(np.abs(z - g["z"]).max()), float(np.abs(g["z"]).max())
-    _LOG.append(f"realistic scale (x_T / 16, {steps} steps): max|z| {zmax:.3f}, ABSOLUTE max-abs deviation {ab:.3e} "
-                f"(relative {ab / zmax:.3e}); north-star bar 1e-3 absolute")
+    _LOG.append(f"x_T / 16, {steps} steps: max|z| {zmax:.2f}, max-abs deviation {ab:.3e} (relative {ab / zmax:.3e})")
+    # one evaluation at a time on the REFERENCE's x_t: is the larger end-to-end deviation the kernels' or the recurrence's?
+    ts, a, ap = _schedule(steps)
+    xt = g["x_traj"]
+    c, uc, ref = mv(inp["c"]), mv(inp["uc"]), inp["ref"].to(dev)
+    curve = []
+    for i in range(steps):
+        want = _guided_eps_from_traj(xt[i], xt[i + 1], a[i], ap[i])
+        xi = torch.from_numpy(xt[i]).to(dev)
+        ti = torch.full((1,), int(ts[i]), dtype=torch.long, device=dev)
+        got = (lambda eu, ec: (eu + 7.0 * (ec - eu)).cpu().numpy())(model.apply_model(xi, ti, c, None, uc=True).clone(),
+                                                                      model.apply_model(xi, ti, c, ref))
+        curve.append(_rel(got, want))
+    _LOG.append(f"x_T / 16: guided eps on the reference x_t per step: max {max(curve):.3e} mean {np.mean(curve):.3e}")
+    assert max(curve) <= TOL_GUIDED, max(curve)          # a single evaluation is as accurate as at the standard scale ...
+    assert ab / zmax <= 9e-3, ab / zmax                  # ... the recurrence amplifies it more (measured 4.6e-3, 2x bound)
+
+
+# ABSOLUTE tolerance of the realistic-scale case = 2x the measured value (profiles/round3_parity_fullsize.txt)
+TOL_ABS_REALISTIC = 8e-3
+
+
+def test_realistic_latent_scale_absolute_deviation(dev):
+    """The north star's "<= 1e-3 max-abs latent deviation" in ABSOLUTE terms at a realistic latent scale: golden c1s_b1_s50 = the
+    configs[1] run with x_T / 16 and the UNet's output conv (the eps prediction) scaled by 0.1, all other weights unchanged, so the
+    50-step trajectory ends at the magnitude of a real SD-1.5 latent.  fp16 MFMA operands bound one eps evaluation at ~1.2e-3 of
+    max|eps| and the free-running latent at ~8e-4 of max|z|: the absolute deviation at this scale is logged
+    and asserted at 2x its measured value -- it is NOT below 1e-3, and DESIGN.md says so."""
+    g = _golden_or_skip("c1s_b1_s50")
+    steps, gain = int(g["steps"]), float(g["eps_gain"])
+    m = H.build_hip_model(320, 8, seed=0, device=dev, image_size=64)
+    with torch.no_grad():
+        m.model.diffusion_model.out[2].weight.mul_(gain)
+        m.model.diffusion_model.out[2].bias.mul_(gain)
+    inp = H.case_inputs(dict(g, x_T=g["x_T"] / float(g["xt_scale"])))
+    mv = lambda d: {k: ([t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in d.items()}  # noqa: E731
+    x_T, ref = torch.from_numpy(g["x_T"]).to(dev), inp["ref"].to(dev)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long, device=dev)
+    c, uc = mv(inp["c"]), mv(inp["uc"])
+    e_c = m.apply_model(x_T, t, c, ref).cpu().numpy()
+    _LOG.append(f"realistic scale: eps_cond max-abs deviation {np.abs(e_c - g['eps_c']).max():.3e} on max|eps| {np.abs(g['eps_c']).max():.3f}")
+    z, _ = m.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
+                        unconditional_conditioning=uc, inpaint=None, x_T=x_T)
+    z = z.cpu().numpy()
+    ab, zmax = float(np.abs(z - g["z"]).max()), float(np.abs(g["z"]).max())
+    _LOG.append(f"realistic scale (x_T / 16, eps conv x {gain}, {steps} steps): max|z| {zmax:.3f}, ABSOLUTE max-abs latent deviation "
+                f"{ab:.3e} (relative {ab / zmax:.3e}); north-star bar: 1e-3 absolute")
     assert zmax <= 12.0, zmax
     assert ab <= TOL_ABS_REALISTIC, ab
-
-
-# absolute tolerance of the realistic-scale case: 2x the measured value (profiles/round3_parity_fullsize.txt)
-TOL_ABS_REALISTIC = 2.0e-2
 
 
 @pytest.fixture(scope="module")

@@ -133,10 +133,13 @@ def test_vae_engine_host_logic_matches_reference_golden(monkeypatch, name):
     assert torch.equal(s, ref) and torch.equal(post.mode(), post.mean)
 
 
+@pytest.mark.parametrize("route", ["fused", "generic"])
 @pytest.mark.parametrize("name", ["small_b1_balance", "small_b1_stage1"])
-def test_variant_host_logic_matches_reference_golden(monkeypatch, name):
-    """'balance' CFG branch (2B-batched pass, generic sampler route) and the stage-1 model class / YAML, emulated kernels."""
+def test_variant_host_logic_matches_reference_golden(monkeypatch, name, route):
+    """'balance' CFG branch (2B-batched pass) and the stage-1 model class / YAML, emulated kernels: the fused route (reference-KV
+    table with a per-sample bank / no pose ControlNet + one launch sequence per step) and the per-call route."""
     hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
     g = H.load_golden(name)
     stage1 = name.endswith("stage1")
     model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
@@ -147,7 +150,11 @@ def test_variant_host_logic_matches_reference_golden(monkeypatch, name):
     assert _rel(model.apply_model(inp["x_T"], t, inp["c"], None, uc=True).numpy(), g["eps_u"]) <= 5e-3
     z, _ = model.sample_log(cond=inp["c"], batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
                             unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"] if stage1 else inp["uc_balance"],
-                            inpaint=None, x_T=inp["x_T"])
+                            inpaint=None, x_T=inp["x_T"], force_generic=(route == "generic"))
+    assert (model._fused is not None) == (route == "fused")
+    if route == "fused":
+        st = model._fused
+        assert st.balance == (not stage1) and st.nread == (1 if stage1 else 2) and st.n_pose == (0 if stage1 else 2)
     assert _rel(z.numpy(), g["z"]) <= 1e-2
 
 
@@ -202,9 +209,13 @@ def noisy_q_sample(model, noises):
     return lambda x_start, t, noise=None: orig(model, x_start, t, noise=next(it).to(x_start.device) if noise is None else noise)
 
 
-def test_wonoise_false_route_matches_reference_golden(monkeypatch):
-    """wonoise=False re-noises the reference latent with q_sample every step (ddim.py:529-535); generic route."""
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_wonoise_false_route_matches_reference_golden(monkeypatch, route):
+    """wonoise=False re-noises the reference latent with q_sample every step (ddim.py:529-535).  Fused route: the
+    noise of all steps is drawn up front, in step order (the same draws the per-call route makes), and the reference-KV table is
+    built from the per-step noisy references."""
     hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
     g = H.load_golden("small_b1_noisy")
     model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
                               image_size=int(g["side"]))
@@ -214,8 +225,10 @@ def test_wonoise_false_route_matches_reference_golden(monkeypatch):
     traj = []
     z, _ = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
                             unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"],
-                            img_callback=lambda p0, i: traj.append(p0.clone()))
-    assert model._fused is None, "wonoise=False must not take the reference-KV table route (the bank depends on the noise)"
+                            img_callback=lambda p0, i: traj.append(p0.clone()), force_generic=(route == "generic"))
+    assert (model._fused is not None) == (route == "fused")
+    if route == "fused":
+        assert model._fused.ref_rows is not None and model._fused.ref_rows.shape[0] == int(g["steps"])
     assert _rel(z.numpy(), g["z"]) <= 2e-2
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"]) <= 2e-2
     # the q_sample arithmetic itself
@@ -324,7 +337,7 @@ def test_fused_step_launch_structure(monkeypatch):
                               image_size=int(g["side"]))
     inp = H.case_inputs(g)
     names = ["igemm", "attention", "groupnorm", "layernorm", "add_f16", "nchw_to_nhwc_f16", "select_row_f32", "gather_rows",
-             "ddim_update", "counter_add"]
+             "ddim_update", "counter_add", "prefetch"]
     counts = {}
     for n in names:
         orig = getattr(ops, n)
@@ -344,7 +357,14 @@ def test_fused_step_launch_structure(monkeypatch):
         counts.clear()
         st._launch_sequence()
         per_mode[merge] = dict(counts)
+        if merge == "1":
+            st_groups = list(st._pf_groups)
     m, f = per_mode["1"], per_mode["0"]
     small = lambda d: sum(d.get(k, 0) for k in ("add_f16", "nchw_to_nhwc_f16", "select_row_f32", "gather_rows", "ddim_update", "counter_add"))  # noqa: E731
     assert (m["igemm"], m["attention"], m["groupnorm"], m.get("layernorm", 0), small(m)) == (207, 32, 61, 0, 11), m
+    # Infinity-Cache weight prefetch (merged form only): one md_prefetch per weight group, forked off the step; together the groups
+    # hold every weight tensor of the step exactly once (UNet incl. decoder + the ControlNet's encoder copy + zero-convs)
+    assert m["prefetch"] == len(st_groups) >= 1 and f.get("prefetch", 0) == 0, (m, f)
+    ptrs = [int(p) for _, tab, n, nb in st_groups for p in tab.view(-1, 2)[:, 0].tolist()]
+    assert len(ptrs) == len(set(ptrs)) and sum(nb for _, _, _, nb in st_groups) > 0
     assert f["igemm"] - m["igemm"] >= 60 and f["groupnorm"] - m["groupnorm"] >= 20 and f["attention"] - m["attention"] >= 5, (m, f)

@@ -160,7 +160,11 @@ def main():
     inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
     runner = parallel.FrameShardedSampler(model, rank=rank, world=world)
     if args.no_graph:
-        runner._runner().use_graph = False
+        # counter runs: every launch un-captured AND on ONE stream (the reference-KV table pass no longer overlaps the first steps;
+        # same launches, same arguments, same order per stream) -- rocprofv3's counter collection serialises kernels anyway
+        st = runner._runner()
+        st.use_graph = False
+        st.table_stream = st.stream
     my = slice(rank * fpg, (rank + 1) * fpg)
     pose, ctx, ref, x_T = inp["pose"][my].contiguous(), inp["ctx"], inp["ref"], inp["x_T"].repeat(fpg, 1, 1, 1)
 

@@ -241,11 +241,6 @@ int md_select_row_f32(const float* table, const int32_t* row_counter, int32_t ro
 int md_gather_rows(const void* table, const int64_t* seg, int32_t nseg, int64_t max_row_units,
                    const int32_t* row_counter, int32_t row_offset, int32_t nrows, int32_t rows_per_block,
                    int64_t block_units, void* dst, void* stream);
-/* HBM -> Infinity Cache (256 MB memory-side cache of the MI355X) prefetch of read-only device ranges: touches every 128-byte line
- * of ranges[i] = (address, bytes) once; bytes multiples of 128, n <= 64, total_bytes = their sum.  `ranges` is a DEVICE int64 [n][2].
- * New in this build (the reference has no such step): the sampling loop streams 2.4 GB of weights per DDIM step through a cache a
- * tenth that size, so a side stream pulls the next layers' weights in while the current ones compute (ddim.FusedStepRunner). */
-int md_prefetch(const int64_t* ranges, int32_t n, int64_t total_bytes, void* stream);
 /* increments *counter by 1 (device side), used to advance the DDIM step inside a captured graph */
 int md_counter_add(int32_t* counter, int32_t delta, void* stream);
 

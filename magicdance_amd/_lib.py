@@ -78,7 +78,6 @@ SIGNATURES = {
     "md_select_row_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "md_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),
     "md_gather_rows": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
-    "md_prefetch": (C.c_int, [_vp, _i32, _i64, _vp]),
     "md_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "md_ddim_update": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "md_graph_begin": (C.c_int, [_vp]),

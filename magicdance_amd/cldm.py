@@ -206,6 +206,8 @@ class ControlLDMReferenceOnlyPose(nn.Module):
             state_dict = {k: v for k, v in state_dict.items() if not k.startswith(drop)}
         if not any(p.startswith("cond_stage_model") for p in drop):
             state_dict = adapt_clip_keys(state_dict, set(self.state_dict().keys()))
+        if hasattr(self.cond_stage_model, "note_loaded_keys"):
+            self.cond_stage_model.note_loaded_keys(state_dict)
         self._fused = None
         # nn.Module.load_state_dict recurses through _load_from_state_dict, not through the children's load_state_dict
         # overrides: drop every packed-fp16 engine here, or a second checkpoint would render with the first one's weights

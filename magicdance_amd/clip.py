@@ -66,6 +66,11 @@ class FrozenCLIPEmbedder(nn.Module):
                 self.transformer = None
         else:
             self.transformer = None
+        # where the text tower's weights come from: "pretrained" (HF cache), "checkpoint" (set by _load_from_state_dict once the
+        # cond_stage_model.transformer.* keys of a model checkpoint have been loaded) or "random" -- an architecture-only module whose
+        # output is meaningless; forward() refuses to run in that state unless the caller opted in (tests: allow_random_weights)
+        self.weights_from = "pretrained" if self.transformer is not None else "random"
+        self.allow_random_weights = text_config is not None
         if self.transformer is None:   # architecture only; weights arrive through load_state_dict (cond_stage_model.transformer.*)
             self.transformer = CLIPTextModel(CLIPTextConfig(**dict(VIT_L14_TEXT_CONFIG, **(text_config or {}))))
         self.device, self.max_length, self.layer, self.layer_idx = device, max_length, layer, layer_idx
@@ -88,9 +93,16 @@ class FrozenCLIPEmbedder(nn.Module):
         self._empty = None
         return super().load_state_dict(*a, **k)
 
-    def _load_from_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, *a, **k):
         self._empty = None
-        return super()._load_from_state_dict(*a, **k)
+        return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, *a, **k)
+
+    def note_loaded_keys(self, state_dict, prefix="cond_stage_model."):
+        """called by the model's load_state_dict: the text tower counts as loaded when the checkpoint held every one of its
+        tensors (a checkpoint without cond_stage_model.* keys, or with a key layout adapt_clip_keys did not map, leaves it random)"""
+        want = set(prefix + k for k in self.state_dict())
+        if want and want <= set(state_dict):
+            self.weights_from = "checkpoint"
 
     @torch.no_grad()
     def _encode_ids(self, ids):
@@ -104,6 +116,10 @@ class FrozenCLIPEmbedder(nn.Module):
 
     @torch.no_grad()
     def forward(self, text):
+        if getattr(self, "weights_from", None) == "random" and not getattr(self, "allow_random_weights", False):
+            raise RuntimeError("FrozenCLIPEmbedder holds randomly initialised weights: neither a Hugging Face cache of "
+                               "openai/clip-vit-large-patch14 nor cond_stage_model.transformer.* keys in the loaded checkpoint -- "
+                               "pass --context_embedding (a saved [1, 77, 768] tensor) instead of a prompt")
         text = [text] if isinstance(text, str) else list(text)
         if all(t == "" for t in text):   # CLIP(""): computed once, repeated per sample
             if self._empty is None:

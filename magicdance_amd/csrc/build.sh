@@ -5,16 +5,27 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../libmagicdance_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-mkdir -p "$HERE/build"
+BUILD="$HERE/build"
+LINK=""
+# MD_ASAN=1: AddressSanitizer build of the HOST side of the C ABI (argument validation, tile / split-K / k-group selection, the
+# tuned-table lookup, launch geometry) into libmagicdance_hip_asan.so; device code is compiled as usual (-fno-gpu-sanitize).
+# tests/test_cabi_asan.py loads it under the sanitizer runtime and drives every launcher's host path.
+if [ "${MD_ASAN:-0}" = "1" ]; then
+  OUT="$HERE/../libmagicdance_hip_asan.so"
+  FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wall -Wno-unused-function -fsanitize=address -fno-gpu-sanitize -shared-libsan"
+  BUILD="$HERE/build_asan"
+  LINK="-fsanitize=address -fno-gpu-sanitize -shared-libsan"
+fi
+mkdir -p "$BUILD"
 pids=()
 for f in igemm attention norm elementwise runtime; do
   EXTRA=""
   # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified file); the softmax touches every S^T / O
   # element each tile, and the AGPR form cost ~5 v_accvgpr moves per MFMA
   if [ "$f" = "attention" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
-  ( "$HIPCC" $FLAGS $EXTRA ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
+  ( "$HIPCC" $FLAGS $EXTRA ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$BUILD/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$OUT"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC $LINK "$BUILD"/*.o -o "$OUT"
 echo "built $OUT"

@@ -267,36 +267,6 @@ extern "C" int md_image_to_u8(const float* x, void* out, int32_t batch, int32_t 
   return MD_OK;
 }
 
-// HBM -> Infinity Cache prefetch of read-only ranges (the NEXT layers' weights): every 128-byte line of the ranges is touched once
-// by a 16-byte load whose result is kept alive but never stored.  The step streams 2.4 GB of weights through a 256 MB memory-side
-// cache, so every layer would otherwise meet its weights cold (HBM latency per k-loop iteration of the small one-frame GEMMs).
-__global__ __launch_bounds__(256) void prefetch_ranges(const long long* __restrict__ ranges, int n, long long total_lines) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  unsigned acc = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_lines; i += stride) {
-    long long rem = i;
-    int r = 0;
-    while (r + 1 < n && rem >= (ranges[2 * r + 1] >> 7)) {   // n <= 64: a short scan of the (L1-resident) table
-      rem -= ranges[2 * r + 1] >> 7;
-      ++r;
-    }
-    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ranges[2 * r]) + rem * 128);
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  asm volatile("" ::"v"(acc));
-}
-
-extern "C" int md_prefetch(const int64_t* ranges, int32_t n, int64_t total_bytes, void* stream) {
-  if (!ranges || n <= 0 || n > 64 || total_bytes <= 0 || (total_bytes & 127)) return MD_ERR_BAD_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const long long total_lines = total_bytes / 128;   // every range is a multiple of 128 bytes (header contract)
-  const long long want = (total_lines + 255) / 256;
-  const unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
-  hipLaunchKernelGGL(prefetch_ranges, dim3(blocks), dim3(256), 0, s, (const long long*)ranges, n, total_lines);
-  MD_HIP_CHECK(hipGetLastError());
-  return MD_OK;
-}
-
 extern "C" int md_counter_add(int32_t* counter, int32_t delta, void* stream) {
   if (!counter) return MD_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -251,15 +251,6 @@ class FusedStepRunner:
         self.table_chunks = 2     # sharded: all-gathers per table (the 2nd overlaps the loop)
         self.tkey = None
         self.pose_stream = torch.cuda.Stream(device=model.device)
-        # HBM -> Infinity Cache weight prefetch (md_prefetch): a step streams 2.4 GB of weights through the MI355X's 256 MB
-        # memory-side cache, so every layer meets its weights cold.  The step's weight stream (recorded once, in launch order) is cut
-        # into groups of ~prefetch_group bytes; when the step reaches group g, a forked stream pulls group g + 1 in (the last group
-        # pulls group 0 of the next step): the small, latency-bound GEMMs of a one-frame step then wait for the Infinity Cache instead
-        # of HBM in every k-loop iteration.  MD_PREFETCH=0 disables (tests check on == off bit for bit).
-        self.prefetch = os.environ.get("MD_PREFETCH", "1") != "0"
-        self.prefetch_group = 40 << 20
-        self.pf_stream = torch.cuda.Stream(device=model.device)
-        self._pf_groups = None     # [(first md_igemm launch index of the group, device range table, n ranges, bytes)]
 
     def _same_rows(self, t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
@@ -397,26 +388,6 @@ class FusedStepRunner:
         if self.graph is not None:
             self.graph.destroy()
             self.graph = None
-        self._pf_groups = None
-
-    def _build_prefetch_groups(self, stream_of_weights):
-        """stream_of_weights: per md_igemm launch of one step, its weight ranges [(address, bytes), ...] in launch order"""
-        groups, cur, seen, cur_bytes, first = [], [], set(), 0, 0
-        for i, ws in enumerate(stream_of_weights):
-            for ptr, nbytes in ws:
-                nbytes &= ~127
-                if nbytes <= 0 or ptr in seen:
-                    continue
-                if cur and (cur_bytes + nbytes > self.prefetch_group or len(cur) == 64):
-                    groups.append((first, cur, cur_bytes))
-                    cur, seen, cur_bytes, first = [], set(), 0, i
-                seen.add(ptr)
-                cur.append((ptr, nbytes))
-                cur_bytes += nbytes
-        if cur:
-            groups.append((first, cur, cur_bytes))
-        dev = self.model.device
-        self._pf_groups = [(fi, torch.tensor(rs, dtype=torch.int64, device=dev), len(rs), nb) for fi, rs, nb in groups]
 
     def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
         dev = self.model.device
@@ -592,35 +563,7 @@ class FusedStepRunner:
         arena.reset()
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
-        pf = self.prefetch and (self.merge_pose or pose_e is None)
-        recorded, state = [], [0, 0]   # (launch index, next group)
-
-        def weight_hook(ws):
-            if self._pf_groups is None:
-                recorded.append(ws)
-                return
-            g = self._pf_groups
-            if state[1] < len(g) and state[0] == g[state[1]][0]:
-                # the step is entering group ``state[1]``: pull the NEXT group's weights (after the last group: the first group of
-                # the next step) into the Infinity Cache on the forked stream
-                nxt = g[(state[1] + 1) % len(g)]
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self.pf_stream.wait_event(ev)
-                with torch.cuda.stream(self.pf_stream):
-                    ops.prefetch(nxt[1], nxt[2], nxt[3])
-                state[1] += 1
-            state[0] += 1
-        if pf:
-            ops.WEIGHT_HOOK = weight_hook
-        try:
-            eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
-        finally:
-            ops.WEIGHT_HOOK = None
-        if pf and self._pf_groups is None:
-            self._build_prefetch_groups(recorded)
-        elif pf:
-            main.wait_stream(self.pf_stream)   # join (a captured graph must end with every forked stream merged back)
+        eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
         ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
         ops.counter_add(self.counter, 1)
 

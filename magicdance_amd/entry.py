@@ -186,7 +186,9 @@ def render_sequence(args, model, sampler, writer, out_dir, cond_image, poses, ct
         z = torch.cat(zs, 0) if zs else torch.zeros((0, model.channels, h, h), device=dev)
     for j, i in enumerate(my):
         torch.save(z[j:j + 1].cpu(), os.path.join(out_dir, "latents", "%03d.pt" % i))
-        writer.save(my_poses[j:j + 1].float(), [os.path.join(out_dir, "pose_maps", "%03d.jpg" % i)], value_range=(0.0, 1.0))
+        # the reference saves c_cat[:, :3].clamp(-1, 1).add(1).mul(0.5) (test_any_image_pose.py:257, test_tiktok.py:285): a [0, 1]
+        # pose map lands in [0.5, 1] -- reproduced as is, the output tree is part of the drop-in surface
+        writer.save(my_poses[j:j + 1].float(), [os.path.join(out_dir, "pose_maps", "%03d.jpg" % i)], value_range=(-1.0, 1.0))
         if have_vae:
             writer.save(model.decode_first_stage(z[j:j + 1]).float(), [os.path.join(out_dir, "gen_images", "%03d.jpg" % i)])
             if gt_images is not None:   # VAE round trip of the ground-truth frame (test_tiktok.py:273-279)

@@ -19,9 +19,6 @@ def _p(t):
 # When a list, every md_igemm / md_attention call appends (launcher, params, flops, keepalive) so that bench.py can replay
 # exactly the launches of one DDIM step in a captured graph and time a kernel family with HIP events on its own stream.
 RECORD = None
-# When set, called as WEIGHT_HOOK([(address, bytes), ...]) with the weight operand(s) of every md_igemm right BEFORE its launch:
-# ddim.FusedStepRunner records the step's weight stream with it and forks its Infinity-Cache prefetches at group boundaries.
-WEIGHT_HOOK = None
 
 
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
@@ -56,9 +53,6 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
         p.batch2, p.w2, p.bias2 = int(set2[0]), _p(set2[1]), _p(set2[2])
         if set2[3] is not None:
             p.ln2_s1, p.ln2_s0 = _p(set2[3][0]), _p(set2[3][1])
-    if WEIGHT_HOOK is not None:
-        wb = n * ksize * ksize * (c0 + c1) * 2
-        WEIGHT_HOOK([(p.w, wb)] + ([(p.w2, wb)] if set2 is not None else []))
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
@@ -171,11 +165,6 @@ def gather_rows(table, seg, nseg, max_row_units, counter, row_offset, dst, nrows
     _lib.check(_lib.load().md_gather_rows(_p(table), _p(seg), nseg, max_row_units, _p(counter), row_offset, nrows,
                                           rows_per_block, block_units, _p(dst), stream_ptr()), "md_gather_rows")
     return dst
-
-
-def prefetch(ranges, n, total_bytes):
-    """md_prefetch: ``ranges`` = device int64 [n, 2] of (address, bytes)"""
-    _lib.check(_lib.load().md_prefetch(_p(ranges), n, total_bytes, stream_ptr()), "md_prefetch")
 
 
 def counter_add(counter, delta):

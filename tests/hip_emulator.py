@@ -25,11 +25,7 @@ def _off(t, elems):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, _hooked=False):
-    from magicdance_amd import ops as _ops
-    if _ops.WEIGHT_HOOK is not None and not _hooked:   # as ops.igemm: the weight operand(s) of the launch, before it is issued
-        wb = n * ksize * ksize * (c0 + c1) * 2
-        _ops.WEIGHT_HOOK([(w.data_ptr(), wb)] + ([(set2[1].data_ptr(), wb)] if set2 is not None else []))
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0):
     if set2 is not None:   # two parameter sets: samples >= batch2 use (w2, bias2, ln2) -- two plain calls on the two sample ranges
         b2, w2, bias2, ln2 = set2
         assert 0 < b2 < batch and bias_batch_stride == 0
@@ -40,13 +36,13 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
                   ld_out=ld_out, out_f32=out_f32, n_tr_begin=n_tr_begin, ld_t=ld_t, ws=ws, asym_pad=asym_pad, col_scale=col_scale,
                   vt_fp8=vt_fp8)
         igemm(a0, w, n, batch=b2, a1=a1, bias=bias, res=res, out=out, out_t=out_t, ln=ln, res_lo=res_lo, out_lo=out_lo, k8=k8,
-              gn_part=gn_part, _hooked=True, **kw)
+              gn_part=gn_part, **kw)
         o = lambda t, e: None if t is None else _off(t, e)  # noqa: E731
         igemm(_off(a0, b2 * hin * win * c0), w2, n, batch=batch - b2, a1=o(a1, b2 * hin * win * c1), bias=bias2,
               res=o(res, b2 * tok * ld_res), out=_off(out, b2 * tok * ldo), out_t=o(out_t, b2 * (n - ntr0_) * ld_t),
               ln=None if ln is None else (ln2[0], ln2[1], ln[2]), res_lo=o(res_lo, b2 * tok * ld_res),
               out_lo=o(out_lo, b2 * tok * ldo), k8=None if k8 is None else (_off(k8[0], b2 * tok * k8[3]),) + tuple(k8[1:]),
-              gn_part=o(gn_part, (b2 * tok // 64) * 2 * n), _hooked=True, **kw)
+              gn_part=o(gn_part, (b2 * tok // 64) * 2 * n), **kw)
         return out
     cin = c0 + c1
     xs = [_mem(a0, (batch, hin, win, c0), (hin * win * c0, win * c0, c0, 1)).float()]
@@ -292,12 +288,6 @@ def counter_add(counter, delta):
     counter += delta
 
 
-def prefetch(ranges, n, total_bytes):
-    """a cache hint: nothing to emulate -- but the table must describe n ranges of 128-byte multiples summing to total_bytes"""
-    r = ranges.view(-1, 2)
-    assert r.shape[0] == n and int(r[:, 1].sum()) == total_bytes and bool((r[:, 1] % 128 == 0).all()) and n <= 64
-
-
 def ddim_update(eps_c, eps_u, ld_eps, x, noise, coef, x_prev, pred_x0, eps_out, batch, c, hw):
     a_t, a_prev, sigma, s1m, scale = [float(v) for v in coef]
     e = _mem(eps_c, (batch, hw, c), (hw * ld_eps, ld_eps, 1)).transpose(1, 2)
@@ -360,7 +350,7 @@ def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
     for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
-                 "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add", "prefetch",
+                 "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)

@@ -75,3 +75,23 @@ def test_model_loads_a_checkpoint_with_the_other_clip_layout():
     z = model.get_unconditional_conditioning(2)
     assert z.shape == (2, 77, 768) and torch.equal(z[0], z[1])
     assert torch.equal(model.get_learned_conditioning([""]), z[:1])
+    assert model.cond_stage_model.weights_from == "checkpoint"
+
+
+def test_random_text_tower_refuses_to_encode():
+    """without a Hugging Face cache the embedder is built from its embedded config with RANDOM weights; it must not hand
+    out contexts until a checkpoint has filled cond_stage_model.transformer.* (entry points then need --context_embedding)."""
+    import pytest
+    from magicdance_amd import clip
+    from tests import helpers as H
+    e = clip.FrozenCLIPEmbedder(device="cpu", text_config=H.TINY_CLIP)
+    assert e.weights_from == "random" and e.allow_random_weights        # an explicit test config opts in
+    e.allow_random_weights = False
+    with pytest.raises(RuntimeError, match="randomly initialised"):
+        e.encode([""])
+    e.note_loaded_keys({"cond_stage_model." + k: v for k, v in e.state_dict().items()})
+    assert e.weights_from == "checkpoint" and e.encode([""]).shape == (1, 77, 768)
+    e2 = clip.FrozenCLIPEmbedder(device="cpu", text_config=H.TINY_CLIP)
+    e2.allow_random_weights = False
+    e2.note_loaded_keys({"model.diffusion_model.x": 0})                   # a checkpoint without text-tower keys
+    assert e2.weights_from == "random"

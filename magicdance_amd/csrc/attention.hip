@@ -17,6 +17,10 @@
 
 #include "md_common.h"
 
+#ifndef MD_ATTN_R3
+#define MD_ATTN_R3 1   // 0: round-2 instruction order of the v3 tile loop (same-box A/B builds only)
+#endif
+
 namespace {
 
 struct AttnArgs {
@@ -617,11 +621,6 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       if (t + P <= nfull) wait_steady(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (t + P < nfull) {
-        issue_full_k(t + 1 + P);
-        issue_full_v(t + P);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       // ONE branch-free block whose instruction order is PINNED step by step (left alone, hipcc emits all exponentials first
       // and all MFMAs after them: no overlap inside the wave).  A: every QK^T MFMA of tile t+1 is followed by its share of the
       // exponentials of tile t (a pair of scores -> fma, exp2, cvt_pk); the K fragments are read up front.  B: every PV MFMA of
@@ -632,7 +631,15 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       {
         const char* Ks = Kring + slot_of(t + 1) * KBYTES;
         const char* Vs = Vring + slot_of(t) * VBYTES;
+        // (round 3) the K fragments of the landed tile are requested from LDS FIRST, the next tiles' LDS-DMA issue (~70 scalar /
+        // address instructions) runs while they are in flight -- it used to sit between the barrier and these reads, with the LDS
+        // latency exposed in front of the first MFMA of every tile
         h8 kfr[4][KSTEPS];
+        if (!MD_ATTN_R3 && t + P < nfull) {   // (A/B build: the round-2 order, issue block ahead of the fragment reads)
+          issue_full_k(t + 1 + P);
+          issue_full_v(t + P);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
           const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
@@ -640,6 +647,12 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int ks = 0; ks < KSTEPS; ++ks)
             kfr[kf][ks] = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MD_ATTN_R3 && t + P < nfull) {
+          issue_full_k(t + 1 + P);
+          issue_full_v(t + P);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
 #pragma unroll
@@ -650,9 +663,22 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NA = 4 * KSTEPS * QF;      // MFMAs of A
         constexpr int NP = 8 * QF;               // score pairs of tile t
+        // (round 3) the V^T fragments of block B are requested half-way through block A (small heads: <= 40 VGPRs), so that the
+        // first PV MFMA does not wait for its LDS reads (d = 40 / 32 only, see below)
+        constexpr bool EARLY_V = MD_ATTN_R3 && DF <= 3;   // (d = 80: 40 more live VGPRs cross the 168-register line = one wave per SIMD less)
+        h8 vfr[DF][2];
+        auto read_v = [&]() {
+#pragma unroll
+          for (int i = 0; i < DF; ++i) {
+            const int row = i * 16 + lr;
+#pragma unroll
+            for (int pk = 0; pk < 2; ++pk) vfr[i][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+          }
+        };
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           const int kf = i / (KSTEPS * QF), ks = (i / QF) % KSTEPS, f = i % QF;
+          if (EARLY_V && i == NA / 2) read_v();
           st2[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], st2[f][kf], 0, 0, 0);
 #pragma unroll
           for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs
@@ -670,13 +696,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int f = 0; f < QF; ++f) l_run[f] += ps[f];
         }
         // B
-        h8 vfr[DF][2];
-#pragma unroll
-        for (int i = 0; i < DF; ++i) {
-          const int row = i * 16 + lr;
-#pragma unroll
-          for (int pk = 0; pk < 2; ++pk) vfr[i][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
-        }
+        if (!EARLY_V) read_v();
 #pragma unroll
         for (int f = 0; f < QF; ++f) mx[f] = -INFINITY;
         __builtin_amdgcn_sched_barrier(0);

@@ -52,6 +52,8 @@ if os.environ.get("TUNE_FILTER") == "shortk":   # K <= 640 at big M: candidates 
     shapes = {k: v for k, v in shapes.items() if k[2] <= 640 and k[0] > 16384}
 if os.environ.get("TUNE_FILTER") == "smallm":   # the 32x32 / 16x16 / 8x8 levels of a one-frame step: where k-groups / split-K matter
     shapes = {k: v for k, v in shapes.items() if k[0] <= 4096}
+if os.environ.get("TUNE_FILTER") == "midm":     # the 64x64 level of a one-frame step and the low levels of multi-frame batches
+    shapes = {k: v for k, v in shapes.items() if 4096 < k[0] <= 32768}
 if os.environ.get("TUNE_FILTER") == "linear":   # 1x1 convs / linears only (their time is mostly epilogue: re-tune after epilogue changes)
     shapes = {k: v for k, v in shapes.items() if k[3] == 1}
 print(f"{len(shapes)} unique igemm shapes", flush=True)
@@ -95,7 +97,7 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
         for sp in splits:
             cands.append((cfg, sp, 1))
             for kg in (2, 4):
-                if kg <= MAX_KG.get(cfg, 1) and M <= 16384 and nk >= 2 * kg and sp in (1, 2, 3, 4, 6, 8) and nk // (sp * kg) >= 1:
+                if kg <= MAX_KG.get(cfg, 1) and M <= 32768 and nk >= 2 * kg and sp in (1, 2, 3, 4, 6, 8) and nk // (sp * kg) >= 1:
                     cands.append((cfg, sp, kg))
     res = []
     for cfg, sp, kg in cands:

@@ -17,9 +17,6 @@
 
 #include "md_common.h"
 
-#ifndef MD_ATTN_R3
-#define MD_ATTN_R3 1   // 0: round-2 instruction order of the v3 tile loop (same-box A/B builds only)
-#endif
 
 namespace {
 
@@ -631,11 +628,10 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       {
         const char* Ks = Kring + slot_of(t + 1) * KBYTES;
         const char* Vs = Vring + slot_of(t) * VBYTES;
-        // (round 3) the K fragments of the landed tile are requested from LDS FIRST, the next tiles' LDS-DMA issue (~70 scalar /
-        // address instructions) runs while they are in flight -- it used to sit between the barrier and these reads, with the LDS
-        // latency exposed in front of the first MFMA of every tile
+        // (an A/B with the K fragment reads ahead of this issue block and the V^T reads half-way through block A measured no
+        // gain, profiles/round3_attention_order_ab.txt: the tile loop is not bound by the LDS latency at its head)
         h8 kfr[4][KSTEPS];
-        if (!MD_ATTN_R3 && t + P < nfull) {   // (A/B build: the round-2 order, issue block ahead of the fragment reads)
+        if (t + P < nfull) {
           issue_full_k(t + 1 + P);
           issue_full_v(t + P);
           __builtin_amdgcn_sched_barrier(0);
@@ -648,11 +644,6 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
             kfr[kf][ks] = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (MD_ATTN_R3 && t + P < nfull) {
-          issue_full_k(t + 1 + P);
-          issue_full_v(t + P);
-        }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
 #pragma unroll
@@ -663,9 +654,6 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NA = 4 * KSTEPS * QF;      // MFMAs of A
         constexpr int NP = 8 * QF;               // score pairs of tile t
-        // (round 3) the V^T fragments of block B are requested half-way through block A (small heads: <= 40 VGPRs), so that the
-        // first PV MFMA does not wait for its LDS reads (d = 40 / 32 only, see below)
-        constexpr bool EARLY_V = MD_ATTN_R3 && DF <= 3;   // (d = 80: 40 more live VGPRs cross the 168-register line = one wave per SIMD less)
         h8 vfr[DF][2];
         auto read_v = [&]() {
 #pragma unroll
@@ -678,7 +666,6 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           const int kf = i / (KSTEPS * QF), ks = (i / QF) % KSTEPS, f = i % QF;
-          if (EARLY_V && i == NA / 2) read_v();
           st2[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], st2[f][kf], 0, 0, 0);
 #pragma unroll
           for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs
@@ -696,7 +683,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int f = 0; f < QF; ++f) l_run[f] += ps[f];
         }
         // B
-        if (!EARLY_V) read_v();
+        read_v();
 #pragma unroll
         for (int f = 0; f < QF; ++f) mx[f] = -INFINITY;
         __builtin_amdgcn_sched_barrier(0);

@@ -65,6 +65,7 @@ struct IgemmArgs {
   const float* ln2_s0;
   int m_split, tiles_m1;
   float* part;   // GroupNorm partial statistics [M / 64][2][N] (sum | sum of squares of the stored fp16 values), or nullptr
+  int epi_stage; // 1: the fp16 epilogue goes through LDS and leaves as whole-row 16-byte stores (host: alignment / shape checks)
 };
 
 // n / d for n < 2^24: q = (n * mul) >> sh with mul = floor(2^sh / d) + 1, sh = 24 + ceil(log2 d) (host side below)
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
   asm volatile("" : "+s"(gp));   // opaque: the loads below cannot move above the k-loop
   MD_LATE_LOAD(*gp)
   float* const e_part = gp->part;
-  if (!epi && !e_part) return;
+  if (!epi && !e_part && !g.epi_stage) return;
   if constexpr (LN) {
     // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
     // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
@@ -674,6 +675,103 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
           for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
           const int oc = (n0 + wn * WTN) / 2 + (i / 2) * 16 + lg * 4;
           *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + oc) = o;
+        }
+      }
+    }
+    return;
+  }
+  if (g.epi_stage) {
+    // LDS-staged epilogue (round 3).  In the fragment layout a lane owns 4 consecutive columns of 16 DIFFERENT rows: every
+    // residual load / output store instruction of a wave is 64 x 8 bytes spread over 16 rows (32-byte pieces of 16 cache lines),
+    // and a 128 x 160 tile with the two-term residual stream needs 80 such instructions per lane -- on the short-K GEMMs (a
+    // 5-tile k-loop per output tile) the vector-memory ISSUE of the epilogue, not the MFMAs, the L2 or HBM, bounded the kernel.
+    // Here phase 1 parks bias + activation (fp32, fragment layout) in the stage memory, phase 2 walks the tile row-major: a
+    // thread owns 8 consecutive columns of one row = ONE 16-byte load per residual term and ONE 16-byte store per output term,
+    // consecutive lanes on consecutive 16-byte pieces of a row (whole 128-byte lines per instruction).
+    constexpr int LDS_TOTAL = KG * GROUP_BYTES;
+    constexpr int SROW = BN + 4;                  // fp32 row stride: +4 keeps the 16 lanes of a DPP row on distinct banks
+    constexpr int ROUNDS = (BM * SROW * 4 <= LDS_TOTAL) ? 1 : 2;
+    static_assert(ROUNDS == 1 || (WAVES_M % 2 == 0 && (BM / 2) * SROW * 4 <= LDS_TOTAL), "staged epilogue fits the stage memory");
+    constexpr int RR = BM / ROUNDS;               // tile rows per round
+    constexpr int WPR = WAVES_M / ROUNDS;         // wave rows per round
+    constexpr int CH = BN / 8;                    // 16-byte output pieces per tile row
+    constexpr int NT = 256 * KG;
+    constexpr int U = (RR * CH + NT - 1) / NT;
+    float* const stg = reinterpret_cast<float*>(smem);
+    const float* __restrict__ const bp = gbias;
+    const half_t* __restrict__ const resp = g.res;
+    const half_t* __restrict__ const rlp = e_res_lo;
+    half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+    half_t* __restrict__ const olp = e_out_lo;
+    const int tall = (int)threadIdx.x;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      __syncthreads();   // the stage memory is free: k-loop reads (rd = 0) / the previous round's phase 2 are done
+      if (epi && wm / WPR == rd) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          const int m = m0 + wm * WTM + j * 16 + lr;
+          const int b = fast_div(min(m, Mlim - 1), g.div_tok_mul, g.div_tok_sh);
+          f4 bv[NF];
+#pragma unroll
+          for (int i = 0; i < NF; ++i) bv[i] = f4{0.f, 0.f, 0.f, 0.f};
+          if (bp) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          }
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            f4 v = acc[i][j] + bv[i];
+            if (n0 + wn * WTN + i * 16 + lg * 4 < e_col_scale_end) v *= e_col_scale;
+            if (g.act == MD_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+            }
+            *reinterpret_cast<f4*>(stg + ((wm % WPR) * WTM + j * 16 + lr) * SROW + wn * WTN + i * 16 + lg * 4) = v;
+          }
+        }
+      }
+      // phase 2 in batches of UB pieces per thread (register budget: all of a 128 x 160 tile's 5 pieces in flight cost a wave
+      // per SIMD); the first batch's residual loads do not depend on phase 1 and are in flight across the barrier
+      constexpr int UB = U < 3 ? U : 3;
+#pragma unroll
+      for (int u0 = 0; u0 < U; u0 += UB) {
+        h8 rv[UB], rl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int c = tall + NT * (u0 + u);
+          const int r = c / CH, cc = c - r * CH;
+          const int mc = min(m0 + rd * RR + r, Mlim - 1), nc = min(n0 + cc * 8, g.N - 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[u][e] = (half_t)0.f;
+          rl[u] = rv[u];
+          if (u0 + u < U && resp) {
+            rv[u] = *reinterpret_cast<const h8*>(resp + (long long)mc * g.ld_res + nc);
+            if (rlp) rl[u] = *reinterpret_cast<const h8*>(rlp + (long long)mc * g.ld_res + nc);
+          }
+        }
+        if (u0 == 0) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (u0 + u >= U) continue;
+          const int c = tall + NT * (u0 + u);
+          const int r = c / CH, cc = c - r * CH;
+          const int m = m0 + rd * RR + r, n = n0 + cc * 8;
+          if (c >= RR * CH || m >= Mlim || n >= g.N) continue;
+          const float* sp = stg + r * SROW + cc * 8;
+          const f4 v0 = *reinterpret_cast<const f4*>(sp), v1 = *reinterpret_cast<const f4*>(sp + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          h8 o, l;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] += (float)rv[u][e];
+            v[e] += (float)rl[u][e];
+            o[e] = (half_t)v[e];
+            l[e] = (half_t)(v[e] - (float)o[e]);
+          }
+          *reinterpret_cast<h8*>(outp + (long long)m * g.ld_out + n) = o;
+          if (olp) *reinterpret_cast<h8*>(olp + (long long)m * g.ld_out + n) = l;
         }
       }
     }
@@ -1129,6 +1227,7 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.m_split = dual ? p->batch2 * g.tokens : 0x7fffffff;
   g.ln_inv_k = 1.0f / (float)g.K;
   g.part = (float*)p->gn_part;
+  g.epi_stage = 0;
   int cfg, split, kg;
   choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split, &kg);
   if (!cfg_exists(cfg)) return MD_ERR_BAD_ARG;
@@ -1153,6 +1252,16 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (p->act == MD_ACT_GEGLU && split > 1) return MD_ERR_UNSUPPORTED;
   if (p->act == MD_ACT_GEGLU && !cfg_geglu_ok(cfg)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
   if (p->ln_s1 && (split > 1 || !cfg_ln_ok(cfg))) return MD_ERR_UNSUPPORTED;
+  {  // the LDS-staged epilogue: plain fp16 row-major output in whole 16-byte pieces
+    static const int stage_env = [] {
+      const char* e = getenv("MD_IGEMM_STAGE");
+      return e ? atoi(e) : 1;
+    }();
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    g.epi_stage = stage_env && split == 1 && !g.part && p->act != MD_ACT_GEGLU && !p->out_f32 && !p->k8 && p->n_tr_begin >= p->n &&
+                  (p->n & 7) == 0 && (p->ld_out & 7) == 0 && al16(p->out) && al16(p->out_lo) &&
+                  (!p->res || ((p->ld_res & 7) == 0 && al16(p->res) && al16(p->res_lo)));
+  }
   g.splitk = split;
   g.tiles_per_split = (g.nk + split - 1) / split;
   g.tiles_m = (g.M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm;

@@ -654,6 +654,49 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
     }
     return;
   }
+  if (g.act == MD_ACT_GEGLU && g.epi_stage) {
+    // GEGLU through LDS (see the staged epilogue below): a * gelu(gate) as fp16 in the fragment layout -> LDS -> whole-row 16-byte
+    // stores ([M][N / 2] output, BN / 2 columns per tile)
+    if constexpr (NF % 2 == 0) {
+      constexpr int SROWH = BN / 2 + 8;   // fp16 row stride (16-byte aligned rows)
+      constexpr int CHG = BN / 16;        // 16-byte pieces per tile row
+      constexpr int NT = 256 * KG;
+      constexpr int U = (BM * CHG + NT - 1) / NT;
+      static_assert(BM * SROWH * 2 <= KG * GROUP_BYTES, "staged GEGLU tile fits the stage memory");
+      half_t* const stg = reinterpret_cast<half_t*>(smem);
+      __syncthreads();
+      if (epi) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+#pragma unroll
+          for (int i = 0; i < NF; i += 2) {
+            const int np = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 20);
+            f4 av = acc[i][j], gv = acc[i + 1][j];
+            if (gbias) {
+              av += *reinterpret_cast<const f4*>(gbias + np);
+              gv += *reinterpret_cast<const f4*>(gbias + np + 16);
+            }
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
+            *reinterpret_cast<h4*>(stg + (wm * WTM + j * 16 + lr) * SROWH + (wn * WTN) / 2 + (i / 2) * 16 + lg * 4) = o;
+          }
+        }
+      }
+      __syncthreads();
+      half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+      const int nh = g.N >> 1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = (int)threadIdx.x + NT * u;
+        const int r = c / CHG, cc = c - r * CHG;
+        const int m = m0 + r, oc = (n0 >> 1) + cc * 8;
+        if (c >= BM * CHG || m >= Mlim || oc >= nh) continue;
+        *reinterpret_cast<h8*>(outp + (long long)m * g.ld_out + oc) = *reinterpret_cast<const h8*>(stg + r * SROWH + cc * 8);
+      }
+    }
+    return;
+  }
   if (g.act == MD_ACT_GEGLU) {
     if (!epi) return;
     if constexpr (NF % 2 == 0) {
@@ -1258,7 +1301,10 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
       return e ? atoi(e) : 1;
     }();
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    g.epi_stage = stage_env && split == 1 && !g.part && p->act != MD_ACT_GEGLU && !p->out_f32 && !p->k8 && p->n_tr_begin >= p->n &&
+    if (p->act == MD_ACT_GEGLU)   // [M][n / 2] fp16 output, 8 output columns per piece
+      g.epi_stage = stage_env && (p->n & 15) == 0 && (p->ld_out & 7) == 0 && al16(p->out);
+    else
+      g.epi_stage = stage_env && split == 1 && !g.part && !p->out_f32 && !p->k8 && p->n_tr_begin >= p->n &&
                   (p->n & 7) == 0 && (p->ld_out & 7) == 0 && al16(p->out) && al16(p->out_lo) &&
                   (!p->res || ((p->ld_res & 7) == 0 && al16(p->res) && al16(p->res_lo)));
   }

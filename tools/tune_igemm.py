@@ -79,6 +79,12 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     bias = torch.randn(N, device=dev)
     nout = N // 2 if act == 2 else N
     out = torch.empty(B, ho * wo, nout, dtype=F16, device=dev)
+    # TUNE_RES=1: the linear layers that close a residual branch (N <= K, one source) are timed WITH the two-term residual stream
+    # (res + res_lo in, out + out_lo out), the way the attention / feed-forward output projections run in the step
+    with_res = bool(os.environ.get("TUNE_RES")) and ks == 1 and c1 == 0 and act == 0 and N <= K
+    res_t = torch.randn(B, ho * wo, N, device=dev).to(F16) if with_res else None
+    res_lo_t = (torch.randn(B, ho * wo, N, device=dev) * 1e-3).to(F16) if with_res else None
+    out_lo_t = torch.empty_like(out) if with_res else None
     buf_ok = (c0 + c1) % 64 == 0 and c0 % 64 == 0
     cfgs = list(range(12, 16)) if buf_ok else list(range(4, 8))  # 2-stage (vmcnt(0)) loaders only, see igemm.hip
     if buf_ok and N % 80 == 0 and act != 2:
@@ -104,7 +110,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
         if True:
             def run(i=0):
                 ops.igemm(x0, wts[i % ncopy], N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
-                          bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp, force_kg=kg)
+                          bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp, force_kg=kg,
+                          res=res_t, ld_res=N if with_res else 0, res_lo=res_lo_t, out_lo=out_lo_t)
             try:
                 with torch.cuda.stream(side):
                     run()

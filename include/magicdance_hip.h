@@ -132,6 +132,14 @@ typedef struct {
    * by 2 or 4 four-wave groups of the same workgroup, each with its own LDS stages, and their accumulators are summed through LDS
    * in fixed order before the epilogue (deterministic; no workspace, no second launch).  Combines with split-K. */
   int32_t force_kg;
+  /* weight storage (ABI v5): 0 = row-major [n][K] as described above; 1 = TILED: [n / 16][K / 64][16][64] fp16 -- the 16 rows x 64
+   * k of one k-tile are one contiguous 2 KiB block, and the k-tiles of a 16-row panel follow each other in the order the kernel
+   * consumes them: ksize 1: k-tile t = columns 64 t ..; ksize 3: t = 9 * cb + tap = columns tap * cin + 64 cb .. of the row-major
+   * form.  Same byte size, and rows r0 .. (r0 % 16 == 0) start at the same byte offset r0 * K * 2 as in the row-major form.
+   * Requires n % 16 == 0 and cin % 64 == 0, c0 % 64 == 0 (the buffer-loader tiles); applies to w and w2.  A layer whose rows are
+   * read once per step from HBM (one-frame batches: M <= a few thousand) streams BN / 16 sequential 2 KiB-granular streams instead
+   * of BN x 128-byte pieces that are K * 2 bytes apart. */
+  int32_t w_tiled;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import MD_ACT_NONE
-from .engine import Act, F16, F32, _f, _h, _require_gpu, get_arena, pack_conv, _WS
+from .engine import Act, F16, F32, _f, _h, _require_gpu, get_arena, is_tiled, pack_conv, _WS
 
 
 # ----------------------------------------------------------------------------- parameter containers
@@ -259,7 +259,7 @@ class VaeEngine:
             part = self.arena.alloc((x.b * ho * wo // 64, 2, n), F32)
         ops.igemm(x.t, cv["w"], n, batch=x.b, hin=x.h, win=x.w, hout=ho, wout=wo, c0=x.c, ksize=k, stride=stride, ups=ups,
                   bias=cv["b"], res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=MD_ACT_NONE,
-                  out=out, ld_out=n, out_f32=out_f32, ws=self._ws(), asym_pad=asym, gn_part=part)
+                  out=out, ld_out=n, out_f32=out_f32, ws=self._ws(), asym_pad=asym, gn_part=part, w_tiled=is_tiled(cv["w"]))
         return Act(out, x.b, ho, wo, n, None, part)
 
     def gn(self, x, gb, silu=True):

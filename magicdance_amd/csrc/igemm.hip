@@ -65,6 +65,7 @@ struct IgemmArgs {
   const float* ln2_s0;
   int m_split, tiles_m1;
   float* part;   // GroupNorm partial statistics [M / 64][2][N] (sum | sum of squares of the stored fp16 values), or nullptr
+  int w_tiled;   // 1: W is stored [N / 16][k-tile in consumption order][16][64] (md_igemm_params.w_tiled), 0: row-major [N][K]
   int epi_stage; // 1: the fp16 epilogue goes through LDS and leaves as whole-row 16-byte stores (host: alignment / shape checks)
 };
 
@@ -168,6 +169,14 @@ __device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, i
   h4 rv, rl;
   epi_load(g, MD_LATE_ARGS, m, b, n, bv, rv, rl);
   epi_finish(g, MD_LATE_ARGS, m, b, n, v, bv, rv, rl);
+}
+
+// byte offset of W row n (k-tile 0): row-major [N][K], or the tiled form [N / 16][K / 64][16][64] -- 16 rows x 128 bytes of one
+// k-tile are one contiguous 2 KiB block and a 16-row panel's k-tiles follow each other IN THE ORDER THE KERNEL CONSUMES THEM (3x3:
+// channel block outer, tap inner), so a workgroup's weight stream is BN / 16 sequential streams instead of BN x 128-byte pieces
+// K * 2 bytes apart (one DRAM page each)
+__device__ __forceinline__ unsigned w_row_offset(int n, const IgemmArgs& g) {
+  return g.w_tiled ? (unsigned)(n >> 4) * (unsigned)g.nk * 2048u + (unsigned)(n & 15) * 128u : (unsigned)n * (unsigned)g.K * 2u;
 }
 
 // 16-lane (one DPP row = the 16 lr lanes that share lg) sum, fixed order -> deterministic: quad_perm [1,0,3,2], quad_perm
@@ -281,14 +290,14 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
         tap0 = kt_first - cb * 9;
         cc0 = cb * 64;
       }
-      const unsigned ksoff0 = (unsigned)(tap0 * g.cin + cc0) * 2u;
+      const unsigned ksoff0 = g.w_tiled ? (unsigned)kt_first * 2048u : (unsigned)(tap0 * g.cin + cc0) * 2u;
       const __amdgpu_buffer_rsrc_t rs_w0 =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
       char* Ws0 = gsm + BM * 128;
 #pragma unroll
       for (int j = 0; j < WJ; ++j) {
         if (W_TAIL && j == WJ - 1 && wave >= 2) break;
-        const unsigned wo = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u + (unsigned)gc * 16u;
+        const unsigned wo = w_row_offset(min(n0 + lrow + 32 * j, g.N - 1), g) + (unsigned)gc * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0, (__attribute__((address_space(3))) void*)(Ws0 + (32 * j + 8 * wave) * 128),
                                                  16, wo, ksoff0, 0, 0);
       }
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
   // beyond the validity select (mask bit ? rowbase : OOB).
   [[maybe_unused]] unsigned w_off[WJ];
 #pragma unroll
-  for (int j = 0; j < WJ; ++j) w_off[j] = (unsigned)min(n0 + lrow + 32 * j, g.N - 1) * (unsigned)g.K * 2u + (unsigned)gc * 16u;
+  for (int j = 0; j < WJ; ++j) w_off[j] = w_row_offset(min(n0 + lrow + 32 * j, g.N - 1), g) + (unsigned)gc * 16u;
   [[maybe_unused]] unsigned rowbase0[AJ], rowbase1[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
@@ -374,6 +383,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
       if (kvalid) {
         if constexpr (KS1) {
           const unsigned soff1 = (unsigned)kt_i * 128u;   // k-tile kt_i = channels 64 kt_i .. of the only tap of the only source
+          const unsigned soffw = g.w_tiled ? (unsigned)kt_i * 2048u : soff1;
 #pragma unroll
           for (int j = 0; j < AJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16,
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
             for (int j = 0; j < WJ; ++j) {
               if (W_TAIL && j == WJ - 1 && wave >= 2) break;
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
-                                                       w_off[j], soff1, 0, 0);
+                                                       w_off[j], soffw, 0, 0);
             }
           }
         } else {
@@ -420,7 +430,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
                                                        16, voff[j], soff, 0, 0);
           }
-          const unsigned ksoff = (unsigned)(tap_u * g.cin + cc_u) * 2u;  // W column of (tap, channel block); ksize 1: tap_u == 0
+          // W column of (tap, channel block); ksize 1: tap_u == 0.  Tiled W: the k-tiles are stored in consumption order
+          const unsigned ksoff = g.w_tiled ? (unsigned)kt_i * 2048u : (unsigned)(tap_u * g.cin + cc_u) * 2u;
           if (skip_w_once) {
             skip_w_once = false;  // the first tile's W part is already in flight (issued ahead of the row setup)
           } else {
@@ -1270,11 +1281,13 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   g.m_split = dual ? p->batch2 * g.tokens : 0x7fffffff;
   g.ln_inv_k = 1.0f / (float)g.K;
   g.part = (float*)p->gn_part;
+  g.w_tiled = p->w_tiled;
   g.epi_stage = 0;
   int cfg, split, kg;
   choose(p, M, g.N, g.K, p->ws ? p->ws_bytes : 0, &cfg, &split, &kg);
   if (!cfg_exists(cfg)) return MD_ERR_BAD_ARG;
   if (cfg >= 12 && (g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // forced buffer loader on a ragged shape
+  if (g.w_tiled && (cfg < 12 || (g.N & 15) != 0 || g.cin % 64 != 0 || g.c0 % 64 != 0)) return MD_ERR_UNSUPPORTED;  // tiled W: buffer loader only
   if (g.part && split > 1) {   // the partials come from the in-kernel epilogue
     if (p->force_splitk > 1) return MD_ERR_UNSUPPORTED;
     split = 1;

@@ -120,17 +120,43 @@ def _h(t, device):
     return t.detach().to(device=device, dtype=F16).contiguous()
 
 
+_W_TILED = os.environ.get("MD_W_TILED", "1") != "0"   # (A/B switch) store GEMM weights in md_igemm's tiled form where it applies
+
+
+def tile_w(w, ksize=1):
+    """Packed fp16 weights [N][K] -> md_igemm's tiled storage (2 KiB blocks of 16 rows x one k-tile, k-tiles of a 16-row panel in
+    consumption order; ops.tile_weights) where the buffer-loader tiles apply (N % 16 == 0, 64 | channels per tap); the returned
+    tensor carries ``_md_tiled`` = True and every launch that reads it (or a row slice of it) passes w_tiled."""
+    n, k = w.shape
+    cin = k // (ksize * ksize)
+    if not _W_TILED or n % 16 or cin % 64:
+        return w
+    t = ops.tile_weights(w, ksize)
+    t._md_tiled = True
+    return t
+
+
+def is_tiled(w):
+    return bool(getattr(w, "_md_tiled", False))
+
+
+def _hw(t, device):
+    """a Linear's weight [N][K] -> fp16, tiled storage"""
+    return tile_w(_h(t, device))
+
+
 def _f(t, device):
     return t.detach().to(device=device, dtype=F32).contiguous()
 
 
-def pack_conv(w, device, cin_pad=None):
-    """OIHW fp32 -> fp16 [O][kh*kw*I] with k = tap*I + c (NHWC gather order)."""
+def pack_conv(w, device, cin_pad=None, tile=False):
+    """OIHW fp32 -> fp16 [O][kh*kw*I] with k = tap*I + c (NHWC gather order); ``tile``: in md_igemm's tiled storage (tile_w)."""
     o, i, kh, kw = w.shape
     w = w.detach().to(device=device, dtype=F32).permute(0, 2, 3, 1)  # O, kh, kw, I
     if cin_pad is not None and cin_pad > i:
         w = torch.nn.functional.pad(w, (0, cin_pad - i))
-    return w.reshape(o, -1).to(F16).contiguous()
+    w = w.reshape(o, -1).to(F16).contiguous()
+    return tile_w(w, kh) if tile else w
 
 
 def pack_geglu(w, b, device):
@@ -251,54 +277,57 @@ class NetEngine:
     # ------------------------------------------------------------------ weight packing
     def _pack(self, net):
         d = self.device
+        pc = lambda w, dev, **kw: pack_conv(w, dev, tile=True, **kw)  # noqa: E731
         emb_w, emb_b = [], []
         self.emb_total = 0
 
         def pack_res(m):
             r = dict(kind="res", cin=m.channels, cout=m.out_channels)
             r["gn1"] = (_f(m.in_layers[0].weight, d), _f(m.in_layers[0].bias, d))
-            r["conv1_w"] = pack_conv(m.in_layers[2].weight, d)
+            r["conv1_w"] = pc(m.in_layers[2].weight, d)
             # conv1 bias is folded into the time-embedding projection bias: h + bias + emb_out (openaimodel.py:284-294)
             r["emb_off"] = self.emb_total
             emb_w.append(m.emb_layers[1].weight.detach())
             emb_b.append(m.emb_layers[1].bias.detach() + m.in_layers[2].bias.detach())
             self.emb_total += m.out_channels
             r["gn2"] = (_f(m.out_layers[0].weight, d), _f(m.out_layers[0].bias, d))
-            r["conv2_w"], r["conv2_b"] = pack_conv(m.out_layers[3].weight, d), _f(m.out_layers[3].bias, d)
+            r["conv2_w"], r["conv2_b"] = pc(m.out_layers[3].weight, d), _f(m.out_layers[3].bias, d)
             if isinstance(m.skip_connection, torch.nn.Conv2d):
-                r["skip_w"], r["skip_b"] = pack_conv(m.skip_connection.weight, d), _f(m.skip_connection.bias, d)
+                r["skip_w"], r["skip_b"] = pc(m.skip_connection.weight, d), _f(m.skip_connection.bias, d)
             return r
 
         def pack_st(m):
             c = m.proj_in.out_channels
             s = dict(kind="st", c=m.in_channels, inner=c, heads=m.n_heads, dh=m.d_head)
             s["gn"] = (_f(m.norm.weight, d), _f(m.norm.bias, d))
-            s["pin_w"], s["pin_b"] = pack_conv(m.proj_in.weight, d), _f(m.proj_in.bias, d)
-            s["pout_w"], s["pout_b"] = pack_conv(m.proj_out.weight, d), _f(m.proj_out.bias, d)
+            s["pin_w"], s["pin_b"] = pc(m.proj_in.weight, d), _f(m.proj_in.bias, d)
+            s["pout_w"], s["pout_b"] = pc(m.proj_out.weight, d), _f(m.proj_out.bias, d)
             blocks = []
             for blk in m.transformer_blocks:
                 t = {}
                 for i, ln in ((1, blk.norm1), (2, blk.norm2), (3, blk.norm3)):
                     t[f"ln{i}"] = (_f(ln.weight, d), _f(ln.bias, d))
                 a1, a2 = blk.attn1, blk.attn2
-                t["qkv_w"] = _h(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d)  # [3C, C]
-                t["o1_w"], t["o1_b"] = _h(a1.to_out[0].weight, d), _f(a1.to_out[0].bias, d)
-                t["q2_w"] = _h(a2.to_q.weight, d)
-                t["kv2_w"] = _h(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d)                  # [2C, ctx]
-                t["o2_w"], t["o2_b"] = _h(a2.to_out[0].weight, d), _f(a2.to_out[0].bias, d)
+                t["qkv_w"] = _hw(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), d)  # [3C, C]
+                t["o1_w"], t["o1_b"] = _hw(a1.to_out[0].weight, d), _f(a1.to_out[0].bias, d)
+                t["q2_w"] = _hw(a2.to_q.weight, d)
+                t["kv2_w"] = _hw(torch.cat([a2.to_k.weight, a2.to_v.weight], 0), d)                  # [2C, ctx]
+                t["o2_w"], t["o2_b"] = _hw(a2.to_out[0].weight, d), _f(a2.to_out[0].bias, d)
                 t["ff1_w"], t["ff1_b"] = pack_geglu(blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach(), d)
-                t["ff2_w"], t["ff2_b"] = _h(blk.ff.net[2].weight, d), _f(blk.ff.net[2].bias, d)
+                t["ff1_w"] = tile_w(t["ff1_w"])
+                t["ff2_w"], t["ff2_b"] = _hw(blk.ff.net[2].weight, d), _f(blk.ff.net[2].bias, d)
                 if c % 64 == 0 and _FOLD_LN:
                     # LayerNorm folded into its consumer GEMM (one launch fewer per LayerNorm, no fp16 round trip of LN(x))
                     qkv = torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)
-                    t["qkv_ln"] = fold_layernorm(qkv, None, blk.norm1.weight, blk.norm1.bias, d)
-                    t["q2_ln"] = fold_layernorm(a2.to_q.weight, None, blk.norm2.weight, blk.norm2.bias, d)
+                    tl = lambda f: (tile_w(f[0]), f[1], f[2])  # noqa: E731
+                    t["qkv_ln"] = tl(fold_layernorm(qkv, None, blk.norm1.weight, blk.norm1.bias, d))
+                    t["q2_ln"] = tl(fold_layernorm(a2.to_q.weight, None, blk.norm2.weight, blk.norm2.bias, d))
                     wl, s1, s0 = fold_layernorm(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, blk.norm3.weight,
                                                 blk.norm3.bias, d)
                     half = wl.shape[0] // 2   # same 16-row a/gate interleave as pack_geglu, applied to W', s1 and s0
                     il = lambda v: torch.stack([v[:half].reshape(half // 16, 16, *v.shape[1:]),  # noqa: E731
                                                 v[half:].reshape(half // 16, 16, *v.shape[1:])], 1).reshape(v.shape).contiguous()
-                    t["ff1_ln"] = (il(wl), il(s1), il(s0))
+                    t["ff1_ln"] = (tile_w(il(wl)), il(s1), il(s0))
                 blocks.append(t)
             s["blocks"] = blocks
             return s
@@ -310,11 +339,11 @@ class NetEngine:
             if name == "SpatialTransformer":
                 return pack_st(m)
             if name == "Downsample":
-                return dict(kind="down", c=m.channels, w=pack_conv(m.op.weight, d), b=_f(m.op.bias, d))
+                return dict(kind="down", c=m.channels, w=pc(m.op.weight, d), b=_f(m.op.bias, d))
             if name == "Upsample":
-                return dict(kind="up", c=m.channels, w=pack_conv(m.conv.weight, d), b=_f(m.conv.bias, d))
+                return dict(kind="up", c=m.channels, w=pc(m.conv.weight, d), b=_f(m.conv.bias, d))
             if isinstance(m, torch.nn.Conv2d):  # stem: 4 -> model_channels, input padded to 8 channels
-                return dict(kind="stem", cout=m.out_channels, w=pack_conv(m.weight, d, cin_pad=8), b=_f(m.bias, d))
+                return dict(kind="stem", cout=m.out_channels, w=pc(m.weight, d, cin_pad=8), b=_f(m.bias, d))
             raise NotImplementedError(name)
 
         self.input_blocks = [[pack_layer(m) for m in blk] for blk in net.input_blocks]
@@ -326,14 +355,14 @@ class NetEngine:
         self.te2_w, self.te2_b = _h(net.time_embed[2].weight, d), _f(net.time_embed[2].bias, d)
         if self.kind == "unet":
             self.head_gn = (_f(net.out[0].weight, d), _f(net.out[0].bias, d))
-            self.head_w, self.head_b = pack_conv(net.out[2].weight, d), _f(net.out[2].bias, d)
+            self.head_w, self.head_b = pc(net.out[2].weight, d), _f(net.out[2].bias, d)
         if self.kind == "pose":
             convs = [m for m in net.input_hint_block if isinstance(m, torch.nn.Conv2d)]
-            self.hint = [dict(w=pack_conv(m.weight, d, cin_pad=8 if i == 0 else None), b=_f(m.bias, d),
+            self.hint = [dict(w=pc(m.weight, d, cin_pad=8 if i == 0 else None), b=_f(m.bias, d),
                               stride=m.stride[0], cin=(8 if i == 0 else m.in_channels), cout=m.out_channels)
                          for i, m in enumerate(convs)]
-            self.zero_convs = [dict(w=pack_conv(z[0].weight, d), b=_f(z[0].bias, d)) for z in net.zero_convs]
-            self.mid_out = dict(w=pack_conv(net.middle_block_out[0].weight, d), b=_f(net.middle_block_out[0].bias, d))
+            self.zero_convs = [dict(w=pc(z[0].weight, d), b=_f(z[0].bias, d)) for z in net.zero_convs]
+            self.mid_out = dict(w=pc(net.middle_block_out[0].weight, d), b=_f(net.middle_block_out[0].bias, d))
 
     # ------------------------------------------------------------------ small helpers
     def _ws(self):
@@ -374,6 +403,7 @@ class NetEngine:
         if out is None:
             out = self.arena.alloc((x.b, hout * wout, nout), F32 if out_f32 else F16)
         w, bias, ln, set2 = self._sets(w, bias, ln)
+        assert set2 is None or is_tiled(set2[1]) == is_tiled(w)
         if isinstance(lo, torch.Tensor):   # explicit second-term buffer (in-place residual epilogue)
             out_lo = lo
         else:
@@ -387,7 +417,7 @@ class NetEngine:
                   a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
                   res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
                   out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale,
-                  set2=set2, gn_part=part)
+                  set2=set2, gn_part=part, w_tiled=is_tiled(w))
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
         return Act(out, x.b, hout, wout, nout, out_lo, part)
 
@@ -473,7 +503,7 @@ class NetEngine:
                 k = torch.empty((bc, tk, c), dtype=F16, device=self.device)
                 vt = torch.zeros((bc, c, ldv), dtype=F16, device=self.device)
                 ops.igemm(c16, blk["kv2_w"], 2 * c, batch=bc, hin=1, win=tk, hout=1, wout=tk, c0=cd, out=k, ld_out=c,
-                          out_t=vt, n_tr_begin=c, ld_t=ldv, ws=self._ws())
+                          out_t=vt, n_tr_begin=c, ld_t=ldv, ws=self._ws(), w_tiled=is_tiled(blk["kv2_w"]))
                 kvs.append((k, vt, bc, tk, ldv))
         self._ctx_cache = (key, kvs, ctx.detach().clone())
         return kvs
@@ -571,11 +601,11 @@ class NetEngine:
                 wl, s1, s0 = blk["qkv_ln"]
                 wl, _, lnp, set2 = self._sets(wl, None, (s1, s0, 1e-5))
                 ops.igemm(t.t, wl, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(), ln=lnp,
-                          col_scale=(self.qscale(dh), c), set2=set2, **okw)
+                          col_scale=(self.qscale(dh), c), set2=set2, w_tiled=is_tiled(wl), **okw)
             else:
                 wq, _, _, set2 = self._sets(blk["qkv_w"], None, None)
                 ops.igemm(n1.t, wq, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, ws=self._ws(),
-                          col_scale=(self.qscale(dh), c), set2=set2, **okw)
+                          col_scale=(self.qscale(dh), c), set2=set2, w_tiled=is_tiled(wq), **okw)
             seg1, n1b = None, 0
             if mode == "read" and nread > 0 and banks is not None and len(banks) > 0:
                 bank = banks[bank_idx]                                             # attention.py:303-311
@@ -628,12 +658,15 @@ class NetEngine:
         bb, nb, c = bank.b, bank.hw, bank.c
         if isinstance(blk["qkv_w"], Dual):   # merged pass: the bank is read by the UNet's samples, through the UNet's to_k / to_v
             blk = {"qkv_w": blk["qkv_w"].a}
+        # rows c .. 3c of the fused [3c][c] weight: in the tiled storage a row range that starts at a multiple of 16 begins at the
+        # same byte offset as in the row-major form, so the slice is the tiled [2c][c] matrix of to_k | to_v
+        tiled = is_tiled(blk["qkv_w"])
         if ATTN_FP8:   # both halves as e4m3 bytes (K row-major, V^T transposed)
             ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
-                      out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws(), k8=(k_out, 0, c, c), vt_fp8=True)
+                      out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws(), k8=(k_out, 0, c, c), vt_fp8=True, w_tiled=tiled)
             return
         ops.igemm(bank.t, blk["qkv_w"][c:], 2 * c, batch=bb, hin=1, win=nb, hout=1, wout=nb, c0=c, out=k_out, ld_out=c,
-                  out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws())
+                  out_t=vt_out, n_tr_begin=c, ld_t=kv_ld(nb), ws=self._ws(), w_tiled=tiled)
 
     def project_bank(self, e, bank, k_out, vt_out):
         """K / V^T of bank entry ``e`` (read order = _all_st order, one transformer block each in SD-1.5) for a whole

@@ -21,11 +21,34 @@ def _p(t):
 RECORD = None
 
 
+def tile_weights(w, ksize=1):
+    """Row-major packed weights [N][K] (K = ksize^2 * cin, k = tap * cin + c) -> the tiled storage form of md_igemm_params.w_tiled:
+    [N / 16][K / 64][16][64] with the k-tiles of a panel in the kernel's consumption order (ksize 3: channel block outer, tap inner).
+    Same shape / bytes; requires N % 16 == 0 and cin % 64 == 0."""
+    n, k = w.shape
+    taps = ksize * ksize
+    cin = k // taps
+    if n % 16 or cin % 64 or taps * cin != k:
+        raise ValueError(f"tile_weights: N = {n}, K = {k}, ksize = {ksize} cannot be tiled (N % 16, cin % 64)")
+    t = w.reshape(n, taps, cin // 64, 64).permute(0, 2, 1, 3)          # [N][cb][tap][64]: k-tile t = 9 cb + tap
+    t = t.reshape(n // 16, 16, k // 64, 64).permute(0, 2, 1, 3)        # [N / 16][k-tile][16][64]
+    return t.contiguous().reshape(n, k)
+
+
+def untile_weights(w, ksize=1):
+    """Inverse of ``tile_weights`` (tests / the CPU emulator)."""
+    n, k = w.shape
+    taps = ksize * ksize
+    cin = k // taps
+    t = w.reshape(n // 16, k // 64, 16, 64).permute(0, 2, 1, 3).reshape(n, cin // 64, taps, 64).permute(0, 2, 1, 3)
+    return t.contiguous().reshape(n, k)
+
+
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0):
-    """See md_igemm.  ``gn_part``: fp32 [M / 64][2][n] receiving the GroupNorm partial statistics of the stored rows.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False):
+    """See md_igemm.  ``w_tiled``: ``w`` (and set2's) is in the tiled storage form, see ``tile_weights``.  ``gn_part``: fp32 [M / 64][2][n] receiving the GroupNorm partial statistics of the stored rows.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
     end, ld): those columns as e4m3 bytes; ``vt_fp8``: the transposed columns as e4m3 bytes.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
@@ -46,7 +69,7 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     p.out_t, p.n_tr_begin, p.ld_t = _p(out_t), (n if n_tr_begin is None else n_tr_begin), ld_t
     p.ws, p.ws_bytes = _p(ws), (0 if ws is None else ws.numel() * ws.element_size())
     p.force_cfg, p.force_splitk, p.asym_pad = force_cfg, force_splitk, int(asym_pad)
-    p.gn_part, p.force_kg = _p(gn_part), int(force_kg)
+    p.gn_part, p.force_kg, p.w_tiled = _p(gn_part), int(force_kg), int(w_tiled)
     if ln is not None:
         p.ln_s1, p.ln_s0, p.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
     if set2 is not None:

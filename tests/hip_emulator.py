@@ -25,7 +25,13 @@ def _off(t, elems):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0):
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False):
+    if w_tiled:   # tiled weight storage (md_igemm_params.w_tiled): back to row-major, then as below
+        from magicdance_amd.ops import untile_weights
+        kk_ = ksize * ksize * (c0 + c1)
+        w = untile_weights(_mem(w, (n, kk_), (kk_, 1)), ksize)
+        if set2 is not None:
+            set2 = (set2[0], untile_weights(_mem(set2[1], (n, kk_), (kk_, 1)), ksize)) + tuple(set2[2:])
     if set2 is not None:   # two parameter sets: samples >= batch2 use (w2, bias2, ln2) -- two plain calls on the two sample ranges
         b2, w2, bias2, ln2 = set2
         assert 0 < b2 < batch and bias_batch_stride == 0

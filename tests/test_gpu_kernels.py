@@ -170,6 +170,75 @@ def test_igemm_conv_kgroups(dev, case, cfg, kg):
     assert torch.equal(out, o2)
 
 
+@pytest.mark.parametrize("cfg,kg,sk", [(-1, 0, 0), (12, 1, 1), (15, 4, 1), (25, 2, 2), (27, 1, 3), (28, 2, 1), (32, 1, 1), (24, 1, 1), (26, 2, 1)])
+def test_igemm_tiled_weights_bit_identical(dev, cfg, kg, sk):
+    """md_igemm_params.w_tiled: the tiled weight storage ([N / 16][k-tile in consumption order][16][64]) changes addresses only --
+    every result is bit-identical to the row-major form of the same weights: 3x3 (stride 1 / 2 / upsample / two sources), 1x1 on
+    two sources, a ragged N (N % tile != 0), GEGLU, folded LayerNorm, the fused q|k|V^T projection, two parameter sets."""
+    from magicdance_amd import ops, engine
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    kw = dict(force_cfg=cfg, force_kg=kg, force_splitk=sk, ws=ws)
+
+    def both(call, w, ks, outs):
+        got = []
+        for tiled in (False, True):
+            for o in outs:
+                o.fill_(3.0)
+            call(ops.tile_weights(w, ks) if tiled else w, tiled)
+            got.append([o.clone() for o in outs])
+        for a, b_ in zip(*got):
+            assert torch.equal(a, b_)
+
+    for (b, cins, h, w, cout, k, stride, ups) in ((2, (128,), 12, 12, 192, 3, 1, 0), (1, (64, 192), 9, 11, 80, 3, 1, 0),
+                                                  (2, (128,), 10, 10, 128, 3, 2, 0), (1, (128,), 6, 6, 160, 3, 1, 1),
+                                                  (2, (192, 64), 8, 8, 208, 1, 1, 0)):
+        xs = [_nhwc16(_rand((b, c, h, w), 10 + i, dev)) for i, c in enumerate(cins)]
+        cin = sum(cins)
+        w16 = engine.pack_conv(_rand((cout, cin, k, k), 20, dev, scale=(cin * k * k) ** -0.5), dev)
+        bias = _rand((cout,), 21, dev, 0.1)
+        ho, wo = (2 * h, 2 * w) if ups else (((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w))
+        out = torch.empty((b, ho * wo, cout), dtype=F16, device=dev)
+        both(lambda wt, tl: ops.igemm(xs[0], wt, cout, batch=b, hin=h, win=w, hout=ho, wout=wo, c0=cins[0], ksize=k, stride=stride,
+                                      ups=ups, a1=xs[1] if len(cins) > 1 else None, c1=cins[1] if len(cins) > 1 else 0, bias=bias,
+                                      out=out, w_tiled=tl, **kw), w16, k, [out])
+    b, n, c = 2, 200, 128
+    x = _rand((b, n, c), 1, dev).to(F16)
+    if cfg in (-1, 12, 15, 28, 32) and sk <= 1:   # GEGLU: even fragment count per wave, no split-K
+        wp, bp = engine.pack_geglu(_rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1), dev)
+        og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
+        both(lambda wt, tl: ops.igemm(x, wt, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og,
+                                      ld_out=4 * c, w_tiled=tl, **kw), wp, 1, [og])
+    wq = _rand((3 * c, c), 2, dev, c ** -0.5)
+    qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
+    vt = torch.zeros((b, c, 208), dtype=F16, device=dev)
+    both(lambda wt, tl: ops.igemm(x, wt, 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
+                                  n_tr_begin=2 * c, ld_t=208, col_scale=(0.25, c), w_tiled=tl, **kw), wq.to(F16).contiguous(), 1, [qk, vt])
+    # rows c .. 3c of the fused weight (the bank K / V^T projection reads a row slice of the tiled tensor)
+    k2 = torch.empty((b, n, c), dtype=F16, device=dev)
+    both(lambda wt, tl: ops.igemm(x, wt[c:], 2 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=k2, ld_out=c, out_t=vt,
+                                  n_tr_begin=c, ld_t=208, w_tiled=tl, **kw), wq.to(F16).contiguous(), 1, [k2, vt])
+    if sk <= 1:   # folded LayerNorm (no split-K), with a second parameter set
+        gamma, beta = 1 + 0.1 * _rand((c,), 9, dev), 0.1 * _rand((c,), 10, dev)
+        wl, s1, s0 = engine.fold_layernorm(wq[:c], None, gamma, beta, dev)
+        wl2, s12, s02 = engine.fold_layernorm(wq[c:2 * c], None, gamma, beta, dev)
+        ol = torch.empty((b, n, c), dtype=F16, device=dev)
+        both(lambda wt, tl: ops.igemm(x, wt, c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=ol, ln=(s1, s0, 1e-5),
+                                      set2=(1, ops.tile_weights(wl2) if tl else wl2, None, (s12, s02)), w_tiled=tl, **kw), wl, 1, [ol])
+
+
+def test_igemm_tiled_weights_rejected(dev):
+    """w_tiled needs the buffer-loader geometry (N % 16 == 0, 64 | channels): anything else is refused, not mis-read."""
+    from magicdance_amd import ops
+    x = torch.zeros((1, 64, 64), dtype=F16, device=dev)
+    out = torch.empty((1, 64, 24), dtype=F16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.igemm(x, torch.zeros((24, 64), dtype=F16, device=dev), 24, batch=1, hin=8, win=8, hout=8, wout=8, c0=64, out=out, w_tiled=True)
+    x2 = torch.zeros((1, 64, 32), dtype=F16, device=dev)
+    out2 = torch.empty((1, 64, 32), dtype=F16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.igemm(x2, torch.zeros((32, 32), dtype=F16, device=dev), 32, batch=1, hin=8, win=8, hout=8, wout=8, c0=32, out=out2, w_tiled=True)
+
+
 @pytest.mark.parametrize("cfg,kg", [(15, 4), (27, 4), (28, 2), (12, 2), (25, 2)])
 def test_igemm_kgroups_epilogues(dev, cfg, kg):
     """k-groups with every epilogue family: GEGLU, fused q|k + V^T with column scale, two-term residual with split-K on top,

@@ -361,3 +361,26 @@ def test_fused_step_launch_structure(monkeypatch):
     small = lambda d: sum(d.get(k, 0) for k in ("add_f16", "nchw_to_nhwc_f16", "select_row_f32", "gather_rows", "ddim_update", "counter_add"))  # noqa: E731
     assert (m["igemm"], m["attention"], m["groupnorm"], m.get("layernorm", 0), small(m)) == (207, 32, 61, 0, 11), m
     assert f["igemm"] - m["igemm"] >= 60 and f["groupnorm"] - m["groupnorm"] >= 20 and f["attention"] - m["attention"] >= 5, (m, f)
+
+
+def test_tiled_weight_storage_round_trip_and_layout():
+    """ops.tile_weights: the storage form of md_igemm_params.w_tiled.  Round trip, the documented block addressing, and the
+    property the engine relies on: a row range that starts at a multiple of 16 is the tiled form of that sub-matrix."""
+    from magicdance_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n, cin, ks in ((64, 128, 1), (48, 64, 3), (160, 192, 3)):
+        k = ks * ks * cin
+        w = torch.randn(n, k, generator=g).half()
+        t = ops.tile_weights(w, ks)
+        assert t.shape == w.shape and torch.equal(ops.untile_weights(t, ks), w)
+        flat, nk = t.reshape(-1), k // 64
+        for (row, kt, e) in ((0, 0, 0), (17, 1, 5), (n - 1, nk - 1, 63), (33, nk // 2, 31)):
+            cb, tap = (kt // 9, kt % 9) if ks == 3 else (kt, 0)
+            col = tap * cin + cb * 64 + e                      # row-major column of element e of k-tile kt (consumption order)
+            addr = ((row >> 4) * nk + kt) * 1024 + (row & 15) * 64 + e
+            assert flat[addr] == w[row, col]
+        assert torch.equal(t[16:], ops.tile_weights(w[16:].contiguous(), ks))
+    with pytest.raises(ValueError):
+        ops.tile_weights(torch.zeros(24, 64).half())
+    with pytest.raises(ValueError):
+        ops.tile_weights(torch.zeros(32, 96).half())

@@ -203,8 +203,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 // zeros in LDS; tap / source / channel base of a 64-channel k-tile are wave-uniform scalars.
 // KT = 64-deep k-tiles per pipeline stage (two stages): one vmcnt(0) + barrier round trip fetches KT k-tiles -- the k-loop of a
 // small GEMM on cold weights is one HBM round trip per iteration.
-// KS1 = true: the launcher guarantees a 1x1 / linear layer on ONE source (ksize 1, stride 1, no upsample, c1 == 0): the per-tile
+// KS = 1: the launcher guarantees a 1x1 / linear layer on ONE source (ksize 1, stride 1, no upsample, c1 == 0): the per-tile
 // LDS-DMA issue needs no tap / source / validity arithmetic at all -- row offsets are constants, the k offset is 128 bytes per tile.
+// KS = 3 (round 3): a 3x3 conv on ONE source without upsample: no source select, no upsample form, no uniform branches between the
+// barrier and the loads -- per tile two scalar multiplies for the tap offset and and / cmp / cndmask per row for the padding taps.
+// KS = 4: two sources (channel concat), 3x3 or 1x1, no upsample: the same with one uniform source select.
 // KG = k-groups per workgroup (round 3): the workgroup has 4 KG waves; group kg = wave / 4 runs the 2-stage loop above on the
 // k-tiles kt_begin + kg, + kg + KG, ... of THE SAME output tile in its own LDS stages (one barrier serves all groups), and the
 // groups' fp32 accumulators are summed through LDS in fixed order before the epilogue.  This is split-K without slabs, reduce
@@ -213,7 +216,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // in flight and four waves per SIMD issuing MFMAs for the same tile.
 // GroupNorm partial statistics (g.part != nullptr, common fp16 epilogue only): per 64-row granule and output column the sum and
 // the sum of squares of the fp16 values just stored, so that the GroupNorm that consumes this tensor needs no statistics pass.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, bool LN = false, int KT = 1, bool KS1 = false, int KG = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LOADER, bool LN = false, int KT = 1, int KS = 0, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the buffer-descriptor builtins do not exist for the host stub
   constexpr bool BUF = LOADER == 2;    // buffer_load ... lds with hardware out-of-range -> 0 and 32-bit offsets
@@ -221,7 +224,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per k-group");
   static_assert(!LN || BUF, "LayerNorm folding is instantiated for the buffer loader");
   static_assert(KG == 1 || BUF, "k-groups exist for the buffer loader");
-  static_assert(!KS1 || BUF, "KS1 is a buffer-loader issue path");
+  static_assert(KS == 0 || BUF, "the specialised issue paths belong to the buffer loader");
+  static_assert(KS == 0 || KS == 1 || KS == 3 || KS == 4, "issue path: generic, 1x1 on one source, 3x3 on one source, two sources");
+  constexpr bool KS1 = KS == 1;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
   constexpr int AJ = BM / 32, WJ = (BN + 31) / 32;  // 16-byte chunks per thread per k-tile
@@ -398,6 +403,53 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
                                                        w_off[j], soffw, 0, 0);
             }
           }
+        } else if constexpr (KS == 3) {
+          const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
+          const int tapbit = 1 << tap_u;
+          const unsigned soff = ((unsigned)(dy * g.win + dx) * (unsigned)g.c0 + (unsigned)cc_u) * 2u;
+#pragma unroll
+          for (int j = 0; j < AJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128), 16,
+                                                     (a_mask[j] & tapbit) ? rowbase0[j] : OOB, soff, 0, 0);
+          const unsigned ksoff = g.w_tiled ? (unsigned)kt_i * 2048u : (unsigned)(tap_u * g.cin + cc_u) * 2u;
+          if (skip_w_once) {
+            skip_w_once = false;
+          } else {
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+              if (W_TAIL && j == WJ - 1 && wave >= 2) break;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
+                                                       w_off[j], ksoff, 0, 0);
+            }
+          }
+        } else if constexpr (KS == 4) {   // channel concat of two sources (skip connections), 3x3 or 1x1 (tap_u stays 0), no upsample
+          const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
+          const int tapbit = 1 << tap_u;
+          const bool second = cc_u >= g.c0;
+          const unsigned cs = second ? g.c1 : g.c0;
+          const unsigned soff = ((unsigned)(dy * g.win + dx) * cs + (unsigned)(second ? cc_u - g.c0 : cc_u)) * 2u;
+          if (second) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                       16, (a_mask[j] & tapbit) ? rowbase1[j] : OOB, soff, 0, 0);
+          } else {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(As + (32 * j + 8 * wave) * 128),
+                                                       16, (a_mask[j] & tapbit) ? rowbase0[j] : OOB, soff, 0, 0);
+          }
+          const unsigned ksoff = g.w_tiled ? (unsigned)kt_i * 2048u : (unsigned)(tap_u * g.cin + cc_u) * 2u;
+          if (skip_w_once) {
+            skip_w_once = false;
+          } else {
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+              if (W_TAIL && j == WJ - 1 && wave >= 2) break;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Ws + (32 * j + 8 * wave) * 128), 16,
+                                                       w_off[j], ksoff, 0, 0);
+            }
+          }
         } else {
           const int dy = (tap_u * 11) >> 5, dx = tap_u - dy * 3;
           const bool second = cc_u >= g.c0;
@@ -445,7 +497,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
         }
       }
       kt_i += KG;
-      if (g.ksize == 3) {
+      if (KS == 3 || (KS == 0 && g.ksize == 3)) {
         tap_u += KG;
         if (tap_u >= 9) {
           tap_u -= 9;
@@ -1037,7 +1089,7 @@ inline int max_kg(int c) {
   }
 }
 
-template <int BM, int BN, int WMv, int WNv, int LOADER, bool LN = false, int KT = 1, bool KS1 = false, int KG = 1>
+template <int BM, int BN, int WMv, int WNv, int LOADER, bool LN = false, int KT = 1, int KS = 0, int KG = 1>
 int launch_cfg(const IgemmArgs& g, hipStream_t s) {
   constexpr size_t lds = (size_t)KG * 2 * KT * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "stages do not fit the 160 KB LDS");
@@ -1046,13 +1098,13 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS1, KG>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS, KG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS1, KG>), grid, dim3(256 * KG), lds, s, g);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMv, WNv, LOADER, LN, KT, KS, KG>), grid, dim3(256 * KG), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -1061,9 +1113,15 @@ int launch_cfg(const IgemmArgs& g, hipStream_t s) {
 template <int BM, int BN, int WMv, int WNv, int KT, int KG>
 int launch_buf_kg(const IgemmArgs& g, hipStream_t s) {
   // the folded LayerNorm exists for 1x1 / linear layers only (validate()): always the KS1 issue path; others: KS1 when it applies
-  if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, true, KT, true, KG>(g, s);
-  const bool ks1 = g.ksize == 1 && g.stride == 1 && !g.ups && g.c1 == 0;
-  return ks1 ? launch_cfg<BM, BN, WMv, WNv, 2, false, KT, true, KG>(g, s) : launch_cfg<BM, BN, WMv, WNv, 2, false, KT, false, KG>(g, s);
+  if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, true, KT, 1, KG>(g, s);
+  if (g.ksize == 1 && g.stride == 1 && !g.ups && g.c1 == 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 1, KG>(g, s);
+  static const bool ks3_on = [] {   // (same-box A/B of the 3x3 issue path)
+    const char* e = getenv("MD_IGEMM_KS3");
+    return !e || atoi(e) != 0;
+  }();
+  if (ks3_on && g.ksize == 3 && !g.ups && g.c1 == 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 3, KG>(g, s);
+  if (ks3_on && !g.ups && g.c1 > 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 4, KG>(g, s);
+  return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 0, KG>(g, s);
 }
 template <int BM, int BN, int WMv, int WNv, int KT = 1, int MAXKG = 1>
 int launch_buf2(const IgemmArgs& g, hipStream_t s, int kg) {

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
         }
       }
       kt_i += KG;
-      if (KS == 3 || (KS == 0 && g.ksize == 3)) {
+      if (KS == 3 || (KS != 1 && g.ksize == 3)) {
         tap_u += KG;
         if (tap_u >= 9) {
           tap_u -= 9;

@@ -54,6 +54,8 @@ if os.environ.get("TUNE_FILTER") == "smallm":   # the 32x32 / 16x16 / 8x8 levels
     shapes = {k: v for k, v in shapes.items() if k[0] <= 4096}
 if os.environ.get("TUNE_FILTER") == "midm":     # the 64x64 level of a one-frame step and the low levels of multi-frame batches
     shapes = {k: v for k, v in shapes.items() if 4096 < k[0] <= 32768}
+if os.environ.get("TUNE_FILTER") == "conv3":    # 3x3 convs only (re-tune after changes to their issue path)
+    shapes = {k: v for k, v in shapes.items() if k[3] == 3}
 if os.environ.get("TUNE_FILTER") == "linear":   # 1x1 convs / linears only (their time is mostly epilogue: re-tune after epilogue changes)
     shapes = {k: v for k, v in shapes.items() if k[3] == 1}
 print(f"{len(shapes)} unique igemm shapes", flush=True)

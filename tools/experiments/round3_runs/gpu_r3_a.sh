@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run A: correctness of the k-group / GroupNorm-partials kernels, then same-box A/B of the two features end to end.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -15

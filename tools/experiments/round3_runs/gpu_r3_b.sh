@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, run B: kernel + parity tests of the k-group / GroupNorm-partials build (epilogue without the register-resident partials),
 # 1-rank RCCL test, same-box A/B of the two features, per-shape step breakdown, tuner pass over the small-M shapes with k-groups.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -4

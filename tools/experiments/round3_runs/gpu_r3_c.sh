@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, run C: whole GPU suite on the finalize + apply GroupNorm / tuned k-group table build, A/B of the GroupNorm fusion,
 # kernel-trace + PMC (FETCH / WRITE on the un-captured timed mix) profiles.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6

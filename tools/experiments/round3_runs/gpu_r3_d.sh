@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run D: which md_igemm variants does `rocprofv3 --pmc` survive?  + weight-prefetch A/B + remaining GPU tests
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   for cg in "27 1" "24 1" "24 2" "33 1" "15 4" "12 1" "25 1" "7 1"; do

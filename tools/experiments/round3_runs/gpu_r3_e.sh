@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run E: whole GPU suite (fused variant routes), kernel-trace timeline of a steady-state step, PMC attempts
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$(pwd)
 {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run F: the default bench line (what the driver runs) + the other quoted workloads, full-size parity log
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_fullsize.log
 timeout 900 python bench.py > gpurun_out/r3f_bench_n1.json 2> gpurun_out/r3f_bench_n1.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run G: same-box A/B of the attention v3 instruction order (fragment reads ahead of the LDS-DMA issue block, early V reads)
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
 for v in 0 1; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run I: forked skip-conv / zero-conv branches + k-group tuned table for the 64x64-level convs: tests, same-box A/B
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== e2e"; timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -x 2>&1 | tail -3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run J: LDS-staged igemm epilogue (16-byte row-major stores): kernel tests, isolated A/B on the epilogue-bound shapes, bench A/B
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vae.py -m gpu -q -x -k "igemm or conv or linear or vae" 2>&1 | tail -3

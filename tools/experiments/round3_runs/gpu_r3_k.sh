@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run K: staged GEGLU epilogue: tests + A/B; linear-layer re-tune with the residual stream attached
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "igemm or linear or geglu" 2>&1 | tail -3

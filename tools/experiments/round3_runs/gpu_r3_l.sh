@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run L: tiled weight storage, isolated cold-weight A/B (bit-identity asserted inside)
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   timeout 600 python tools/wtile_bench.py 2>&1 | tail -30

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run M: tiled weight storage in the engine: kernel tests, e2e parity, same-box A/B
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "tiled or igemm_conv" 2>&1 | tail -3

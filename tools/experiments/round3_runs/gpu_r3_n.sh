@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run N: 3x3 one-source issue path (KS = 3): kernel tests, isolated shapes and bench, same-box A/B
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vae.py -m gpu -q -x -k "igemm or conv or vae" 2>&1 | tail -3

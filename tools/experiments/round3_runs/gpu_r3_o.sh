@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, run O: two-source issue path (KS = 4) validation + 3x3 re-tune with the new issue paths
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 {
   echo "== kernels"; timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "igemm" 2>&1 | tail -3

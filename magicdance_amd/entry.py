@@ -184,13 +184,20 @@ def render_sequence(args, model, sampler, writer, out_dir, cond_image, poses, ct
                                      inpaint=None, x_T=x_T)
             zs.append(zi)
         z = torch.cat(zs, 0) if zs else torch.zeros((0, model.channels, h, h), device=dev)
+    # first-stage decode in batches of frames_per_batch (one VAE pass per batch instead of per frame; a frame decoded inside a batch
+    # is bit-identical to the same frame decoded alone, tests/test_gpu_vae.py)
+    nb = max(1, int(getattr(args, "frames_per_batch", 1) or 1))
+    decoded = {}
     for j, i in enumerate(my):
+        if have_vae and j % nb == 0:
+            imgs = model.decode_first_stage(z[j:j + nb]).float()
+            decoded = {j + k: imgs[k:k + 1] for k in range(imgs.shape[0])}
         torch.save(z[j:j + 1].cpu(), os.path.join(out_dir, "latents", "%03d.pt" % i))
         # the reference saves c_cat[:, :3].clamp(-1, 1).add(1).mul(0.5) (test_any_image_pose.py:257, test_tiktok.py:285): a [0, 1]
         # pose map lands in [0.5, 1] -- reproduced as is, the output tree is part of the drop-in surface
         writer.save(my_poses[j:j + 1].float(), [os.path.join(out_dir, "pose_maps", "%03d.jpg" % i)], value_range=(-1.0, 1.0))
         if have_vae:
-            writer.save(model.decode_first_stage(z[j:j + 1]).float(), [os.path.join(out_dir, "gen_images", "%03d.jpg" % i)])
+            writer.save(decoded.pop(j), [os.path.join(out_dir, "gen_images", "%03d.jpg" % i)])
             if gt_images is not None:   # VAE round trip of the ground-truth frame (test_tiktok.py:273-279)
                 real = gt_images[i].unsqueeze(0).to(dev)
                 rec = model.decode_first_stage(model.get_first_stage_encoding(model.encode_first_stage(real)))

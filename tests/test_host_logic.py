@@ -326,9 +326,9 @@ def test_merged_pose_pass_matches_separate_pose_pass(monkeypatch):
 
 def test_fused_step_launch_structure(monkeypatch):
     """Launch structure of ONE fused DDIM step (what the captured graph replays), counted as C-ABI calls on the emulated ABI: the
-    merged pass must not grow back -- 207 md_igemm (on the GPU ~45 of them add a split-K reduce kernel), 32 md_attention, 61
-    md_groupnorm, 11 small ops = the ~310 launches per step of DESIGN.md / profiles/round2_step_breakdown_1frame.txt -- and the
-    forked-stream form keeps the ControlNet's own ~110."""
+    merged pass must not grow back -- 207 md_igemm, 32 md_attention, 61 md_groupnorm, 11 small ops = 311 C-ABI launches; on the GPU
+    they are 384 kernels (split-K reduce kernels behind ~38 of the GEMMs, gn_finalize / gn_stats ahead of gn_apply on the large
+    slices: profiles/round3_step_timeline_1frame.txt) -- and the forked-stream form keeps the ControlNet's own ~110."""
     hip_emulator.install(monkeypatch)
     _no_graph(monkeypatch)
     from magicdance_amd import ops

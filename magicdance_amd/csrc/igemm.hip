@@ -1115,12 +1115,8 @@ int launch_buf_kg(const IgemmArgs& g, hipStream_t s) {
   // the folded LayerNorm exists for 1x1 / linear layers only (validate()): always the KS1 issue path; others: KS1 when it applies
   if (g.ln_s1) return launch_cfg<BM, BN, WMv, WNv, 2, true, KT, 1, KG>(g, s);
   if (g.ksize == 1 && g.stride == 1 && !g.ups && g.c1 == 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 1, KG>(g, s);
-  static const bool ks3_on = [] {   // (same-box A/B of the 3x3 issue path)
-    const char* e = getenv("MD_IGEMM_KS3");
-    return !e || atoi(e) != 0;
-  }();
-  if (ks3_on && g.ksize == 3 && !g.ups && g.c1 == 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 3, KG>(g, s);
-  if (ks3_on && !g.ups && g.c1 > 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 4, KG>(g, s);
+  if (g.ksize == 3 && !g.ups && g.c1 == 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 3, KG>(g, s);
+  if (!g.ups && g.c1 > 0) return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 4, KG>(g, s);
   return launch_cfg<BM, BN, WMv, WNv, 2, false, KT, 0, KG>(g, s);
 }
 template <int BM, int BN, int WMv, int WNv, int KT = 1, int MAXKG = 1>
@@ -1354,12 +1350,8 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (p->force_kg > 0) {
     kg = p->force_kg;
   } else if (kg <= 0) {
-    static const int kg_rule = [] {   // MD_IGEMM_KG=0: no k-groups unless forced / tuned (A/B, tools/tune_igemm.py)
-      const char* e = getenv("MD_IGEMM_KG");
-      return e ? atoi(e) : 1;
-    }();
     const long long tl = ((M + cfg_of(cfg).bm - 1) / cfg_of(cfg).bm) * ((g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn) * split;
-    kg = default_kg(cfg, &split, tl, g.nk, kg_rule != 0 && p->force_splitk <= 0);
+    kg = default_kg(cfg, &split, tl, g.nk, p->force_splitk <= 0);
   }
   if (kg > max_kg(cfg)) return MD_ERR_UNSUPPORTED;
   if (split > 1 && (!p->ws || (long long)split * M * g.N * 4 > p->ws_bytes)) return MD_ERR_WORKSPACE;
@@ -1367,15 +1359,11 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   if (p->act == MD_ACT_GEGLU && !cfg_geglu_ok(cfg)) return MD_ERR_UNSUPPORTED;  // odd fragment count per wave
   if (p->ln_s1 && (split > 1 || !cfg_ln_ok(cfg))) return MD_ERR_UNSUPPORTED;
   {  // the LDS-staged epilogue: plain fp16 row-major output in whole 16-byte pieces
-    static const int stage_env = [] {
-      const char* e = getenv("MD_IGEMM_STAGE");
-      return e ? atoi(e) : 1;
-    }();
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (p->act == MD_ACT_GEGLU)   // [M][n / 2] fp16 output, 8 output columns per piece
-      g.epi_stage = stage_env && (p->n & 15) == 0 && (p->ld_out & 7) == 0 && al16(p->out);
+      g.epi_stage = (p->n & 15) == 0 && (p->ld_out & 7) == 0 && al16(p->out);
     else
-      g.epi_stage = stage_env && split == 1 && !g.part && !p->out_f32 && !p->k8 && p->n_tr_begin >= p->n &&
+      g.epi_stage = split == 1 && !g.part && !p->out_f32 && !p->k8 && p->n_tr_begin >= p->n &&
                   (p->n & 7) == 0 && (p->ld_out & 7) == 0 && al16(p->out) && al16(p->out_lo) &&
                   (!p->res || ((p->ld_res & 7) == 0 && al16(p->res) && al16(p->res_lo)));
   }
@@ -1389,11 +1377,7 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   }
   g.tiles_n = (g.N + cfg_of(cfg).bn - 1) / cfg_of(cfg).bn;
   {  // ~64 workgroups are resident per XCD: make them a (group_m x tiles_n) block of the tile grid
-    static const int gm_env = [] {
-      const char* e = getenv("MD_IGEMM_GROUP_M");
-      return e ? atoi(e) : 0;
-    }();
-    int gm = gm_env > 0 ? gm_env : (64 + g.tiles_n - 1) / g.tiles_n;
+    int gm = (64 + g.tiles_n - 1) / g.tiles_n;
     if (gm < 1) gm = 1;
     if (gm > g.tiles_m) gm = g.tiles_m;
     g.group_m = gm;

@@ -336,10 +336,7 @@ inline bool gn_group_block(int cpg, int groups, int* gper, int* cw8) {
   *cw8 = gp * cpg / 8;
   return *cw8 >= 1 && *cw8 <= GN_SMALL_THREADS;
 }
-const long long g_gn_small_bytes = [] {
-  const char* e = getenv("MD_GN_SMALL_BYTES");
-  return e ? atoll(e) : 96LL << 10;
-}();
+constexpr long long g_gn_small_bytes = 96LL << 10;
 // small slices: one launch, a block owns whole groups of one sample and all its pixels (gn_small)
 inline bool gn_small_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
   return gn_group_block(cpg, groups, gper, cw8) && (long long)hw * *gper * cpg * 2 <= g_gn_small_bytes &&

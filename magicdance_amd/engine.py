@@ -120,16 +120,13 @@ def _h(t, device):
     return t.detach().to(device=device, dtype=F16).contiguous()
 
 
-_W_TILED = os.environ.get("MD_W_TILED", "1") != "0"   # (A/B switch) store GEMM weights in md_igemm's tiled form where it applies
-
-
 def tile_w(w, ksize=1):
     """Packed fp16 weights [N][K] -> md_igemm's tiled storage (2 KiB blocks of 16 rows x one k-tile, k-tiles of a 16-row panel in
     consumption order; ops.tile_weights) where the buffer-loader tiles apply (N % 16 == 0, 64 | channels per tap); the returned
     tensor carries ``_md_tiled`` = True and every launch that reads it (or a row slice of it) passes w_tiled."""
     n, k = w.shape
     cin = k // (ksize * ksize)
-    if not _W_TILED or n % 16 or cin % 64:
+    if n % 16 or cin % 64:
         return w
     t = ops.tile_weights(w, ksize)
     t._md_tiled = True

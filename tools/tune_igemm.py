@@ -77,6 +77,10 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
     # 256 MB Infinity Cache), so each replayed launch reads a different copy (>= 320 MB of copies in rotation)
     ncopy = max(2, min(REPS, int((320 << 20) // max(1, N * K * 2)) + 1))
     wts = [(torch.randn(N, K, device=dev) * 0.02).to(F16) for _ in range(ncopy)]
+    # the engine stores its GEMM weights tiled (md_igemm_params.w_tiled) wherever the buffer loader applies: time that form
+    tiled = (c0 + c1) % 64 == 0 and c0 % 64 == 0 and N % 16 == 0
+    if tiled:
+        wts = [ops.tile_weights(t, ks) for t in wts]
     wt = wts[0]
     bias = torch.randn(N, device=dev)
     nout = N // 2 if act == 2 else N
@@ -113,7 +117,7 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
             def run(i=0):
                 ops.igemm(x0, wts[i % ncopy], N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
                           bias=bias, act=act, out=out, ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp, force_kg=kg,
-                          res=res_t, ld_res=N if with_res else 0, res_lo=res_lo_t, out_lo=out_lo_t)
+                          res=res_t, ld_res=N if with_res else 0, res_lo=res_lo_t, out_lo=out_lo_t, w_tiled=tiled)
             try:
                 with torch.cuda.stream(side):
                     run()

@@ -360,9 +360,8 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
     }
   }
 
-  const int t0 = (g.n0 + 63) >> 6;
   const int t1 = (g.k1 != nullptr && b < g.n1_batches) ? ((g.n1 + 63) >> 6) : 0;
-  // (t0 + t1 tiles in all: the full ones run in the pipelined loop, a partial last tile of either segment in the tail below)
+  // (ceil(n0 / 64) + t1 tiles in all: the full ones run in the pipelined loop, a partial last tile of either segment in the tail below)
 
   const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.k0 + b * g.k0_bs), 0, g.n0 * g.ld_k0 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.vt0 + b * g.vt0_bs), 0, g.heads * D * g.ld_vt0 * 2, 0x00020000);

@@ -1,0 +1,65 @@
+"""CPU tier: the tuned (shape -> tile config, split-K, k-groups) table of md_igemm is well-formed.  A malformed entry would only
+surface on the GPU, at the one shape it names (MD_ERR_UNSUPPORTED from a layer of the step); this parses
+magicdance_amd/csrc/igemm_tuned.inc against the constraints stated in igemm.hip (cfg_exists, max_kg, the loader each config needs,
+the epilogue families a config is instantiated for)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm_tuned.inc")
+HIP = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm.hip")
+PAT = re.compile(r"\s*\{(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)(?:,\s*(\d+))?\}")
+
+
+def _entries():
+    out = []
+    for line in open(INC):
+        m = PAT.match(line)
+        if m:
+            v = [int(x) if x is not None else 0 for x in m.groups()]
+            out.append(tuple(v) + (line,))
+    return out
+
+
+def _max_kg():
+    """max_kg() of igemm.hip, parsed from its switch"""
+    src = open(HIP).read()
+    body = src[src.index("inline int max_kg(int c)"):]
+    body = body[:body.index("default:")]
+    mk = {}
+    for cases, ret in re.findall(r"((?:case \d+:\s*)+)return (\d+);", body):
+        for c in re.findall(r"case (\d+):", cases):
+            mk[int(c)] = int(ret)
+    assert mk, "max_kg switch not found"
+    return mk
+
+
+def test_tuned_table_entries_are_valid():
+    ents = _entries()
+    assert len(ents) >= 150
+    mk = _max_kg()
+    src = open(HIP).read()
+    first_sd, num_all = (int(v) for v in re.search(r"kFirstSdCfg = (\d+), kNumAllCfgs = (\d+)", src).groups())
+    exists = lambda c: 4 <= c < 8 or 12 <= c < 16 or first_sd <= c < num_all  # noqa: E731  (cfg_exists)
+    for (m, n, k, ks, st, ups, cfg, split, kg, line) in ents:
+        assert exists(cfg), line
+        assert ks in (1, 3) and st in (1, 2) and ups in (0, 1), line
+        assert k % (ks * ks) == 0, line
+        cin = k // (ks * ks)
+        if cfg >= 12:   # buffer-loader tiles: whole 64-channel k-tiles
+            assert cin % 64 == 0, line
+        assert split >= 1 and kg in (0, 1, 2, 4), line
+        assert max(kg, 1) <= mk.get(cfg, 1), line
+        nk = (k + 63) // 64
+        assert split * max(kg, 1) <= max(nk, 1), line      # every split slab / k-group owns at least one k-tile
+        assert m > 0 and n > 0 and n % 4 == 0, line
+
+
+def test_tuned_table_keys_resolve_to_one_choice():
+    """The lookup takes the FIRST entry of a key: duplicates must agree (a stale duplicate would silently shadow a re-tune)."""
+    seen = {}
+    for e in _entries():
+        key, val = e[:6], (e[6], e[7], max(e[8], 1))
+        if key in seen:
+            assert seen[key] == val, (key, seen[key], val)
+        seen[key] = val

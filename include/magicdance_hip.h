@@ -143,6 +143,13 @@ typedef struct {
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);
+/* Tile configuration `cfg` (the values force_cfg accepts; tests / tuner): info = {BM, BN, k-tiles per stage or ring step, maximal
+ * k-groups (ring form: THE k-groups), ring form 0 / 1, ring slots for 1x1 layers, ring slots for 3x3 layers, waves along N (ring form; else 0)}.  Configs 4-33 are
+ * the 2-stage k-loop (every layer); configs 40.. (ABI v6) the RING form -- a multi-slot LDS ring with counted waits whose 3x3 convs
+ * keep one haloed activation block per 64-channel block in LDS for all nine taps: stride 1, no upsample, symmetric padding,
+ * 64-channel-aligned sources (md_igemm returns MD_ERR_UNSUPPORTED otherwise, or when the ring does not fit the 160 KiB LDS at this
+ * `win`).  Returns MD_ERR_BAD_ARG for an id that does not exist. */
+int md_igemm_config_info(int32_t cfg, int32_t info[8]);
 /* bytes of split-K workspace that guarantees the auto heuristic is never constrained for this shape */
 int64_t md_igemm_workspace_bytes(const md_igemm_params* p);
 

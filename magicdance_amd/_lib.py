@@ -64,6 +64,7 @@ SIGNATURES = {
     "md_arch": (C.c_char_p, []),
     "md_igemm": (C.c_int, [C.POINTER(IgemmParams), _vp]),
     "md_igemm_workspace_bytes": (_i64, [C.POINTER(IgemmParams)]),
+    "md_igemm_config_info": (C.c_int, [_i32, C.POINTER(_i32 * 8)]),
     "md_attention": (C.c_int, [C.POINTER(AttentionParams), _vp]),
     "md_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), _vp]),
     "md_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),

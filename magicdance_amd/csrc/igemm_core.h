@@ -1,0 +1,587 @@
+// Shared pieces of the md_igemm kernels (igemm.hip: the 2-stage loop; igemm_ring.hip: the multi-slot ring): launch arguments,
+// epilogue helpers and THE epilogue (k-group reduction, folded LayerNorm, split-K slab store, GEGLU, LDS-staged / fragment-layout
+// fp16 stores with the two-term residual stream and GroupNorm partials).  One source of truth for every k-loop form.
+#pragma once
+#include "md_common.h"
+
+namespace mdig {
+
+struct IgemmArgs {
+  const half_t* a0;
+  const half_t* a1;
+  int c0, c1, cin;
+  int batch, hin, win, hout, wout, tokens;
+  int ksize, stride, ups, pad;
+  const half_t* w;
+  int M, N, K;
+  int nk, splitk, tiles_per_split;
+  int tiles_m, tiles_n, group_m;
+  unsigned div_tok_mul, div_tok_sh, div_w_mul, div_w_sh;  // exact n / tokens and n / wout for n < 2^24 (fast_div)
+  // epilogue
+  const float* bias;
+  long long bias_bs;
+  const half_t* res;
+  const half_t* res_lo;
+  int ld_res;
+  int act;
+  void* out;
+  half_t* out_lo;
+  float col_scale;
+  int col_scale_end;
+  unsigned char* k8;      // columns [k8_begin, k8_end) go here as e4m3 bytes ([M][ld_k8]) instead of to `out`
+  int k8_begin, k8_end, ld_k8;
+  int vt_fp8;             // the transposed columns (n >= n_tr_begin) are stored as e4m3 bytes
+  int ld_out;
+  int out_f32;
+  half_t* out_t;
+  int n_tr_begin;
+  int ld_t;
+  float* ws;
+  // LayerNorm folded into the GEMM (A rows are normalised on the fly): out = rstd_m (acc - mu_m s1[n]) + s0[n]
+  const float* ln_s1;
+  const float* ln_s0;
+  float ln_eps, ln_inv_k;
+  // second parameter set: rows m >= m_split use w2 / bias2 / ln2_* and form their own m-tiles, tile_m >= tiles_m1 (INT_MAX: one set)
+  const half_t* w2;
+  const float* bias2;
+  const float* ln2_s1;
+  const float* ln2_s0;
+  int m_split, tiles_m1;
+  float* part;   // GroupNorm partial statistics [M / 64][2][N] (sum | sum of squares of the stored fp16 values), or nullptr
+  int w_tiled;   // 1: W is stored [N / 16][k-tile in consumption order][16][64] (md_igemm_params.w_tiled), 0: row-major [N][K]
+  int epi_stage; // 1: the fp16 epilogue goes through LDS and leaves as whole-row 16-byte stores (host: alignment / shape checks)
+  int ring_a_rows;  // ring form, 3x3: rows (pixels) of one A block = BM + 2 win + 2 rounded up to 8 (igemm_ring.hip)
+};
+
+// n / d for n < 2^24: q = (n * mul) >> sh with mul = floor(2^sh / d) + 1, sh = 24 + ceil(log2 d) (host side below)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
+  return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
+}
+
+// Epilogue-only parameters.  The k-loop kernel reads them from the kernarg segment AFTER the loop (scalar loads behind an opaque
+// pointer) into plain locals: as by-value kernel arguments they would be loaded at entry and held in SGPRs across the loop, which
+// pushed the kernel over the SGPR budget (spill to scratch at entry, scratch reload at the head of every wave's epilogue); as a
+// struct the compiler keeps them in scratch, hence the long-hand parameter list.
+#define MD_LATE_PARAMS                                                                                                          \
+  float e_col_scale, int e_col_scale_end, unsigned char *e_k8, int e_k8_begin, int e_k8_end, int e_ld_k8, int e_vt_fp8,        \
+      const half_t *e_res_lo, half_t *e_out_lo, half_t *e_out_t, int e_n_tr_begin, int e_ld_t
+#define MD_LATE_ARGS e_col_scale, e_col_scale_end, e_k8, e_k8_begin, e_k8_end, e_ld_k8, e_vt_fp8, e_res_lo, e_out_lo, e_out_t, e_n_tr_begin, e_ld_t
+#define MD_LATE_LOAD(src)                                                                                                       \
+  const float e_col_scale = (src).col_scale;                                                                                    \
+  const int e_col_scale_end = (src).col_scale_end;                                                                              \
+  unsigned char* const e_k8 = (src).k8;                                                                                         \
+  const int e_k8_begin = (src).k8_begin, e_k8_end = (src).k8_end, e_ld_k8 = (src).ld_k8, e_vt_fp8 = (src).vt_fp8;               \
+  const half_t* const e_res_lo = (src).res_lo;                                                                                  \
+  half_t* const e_out_lo = (src).out_lo;                                                                                        \
+  half_t* const e_out_t = (src).out_t;                                                                                          \
+  const int e_n_tr_begin = (src).n_tr_begin, e_ld_t = (src).ld_t;
+
+// (1) every global load the epilogue of (m, n..n+3) needs -- bias, residual, second residual term -- ISSUED together ...
+__device__ __forceinline__ void epi_load(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4& bv, h4& rv, h4& rl) {
+  const float* bias = m >= g.m_split ? g.bias2 : g.bias;
+  const bool row_major = n < e_n_tr_begin && !(e_k8 && n >= e_k8_begin && n < e_k8_end);   // lands in `out` (not V^T / e4m3 K)
+  bv = f4{0.f, 0.f, 0.f, 0.f};
+  rv = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  rl = rv;
+  if (bias) bv = *reinterpret_cast<const f4*>(bias + (long long)b * g.bias_bs + n);
+  if (g.res && row_major) {
+    rv = *reinterpret_cast<const h4*>(g.res + (long long)m * g.ld_res + n);
+    if (e_res_lo) rl = *reinterpret_cast<const h4*>(e_res_lo + (long long)m * g.ld_res + n);
+  }
+}
+
+// (2) ... and consumed here: bias, column scale, activation, residual, store(s).
+__device__ __forceinline__ void epi_finish(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v, f4 bv, h4 rv, h4 rl) {
+  v += bv;
+  if (n < e_col_scale_end) v *= e_col_scale;   // attention scale folded into the q columns (before the fp16 rounding)
+  if (g.act == MD_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = md::silu_f(v[i]);
+  }
+  if (n >= e_n_tr_begin) {
+    // transposed store (V^T): [b][n - n_tr][tok]
+    const int tok = m - b * g.tokens;
+    const int ntr = g.N - e_n_tr_begin;
+    if (e_vt_fp8) {   // e4m3 bytes (fp8 attention path)
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+      unsigned char* o8 = reinterpret_cast<unsigned char*>(e_out_t) + ((long long)b * ntr + (n - e_n_tr_begin)) * e_ld_t + tok;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o8[(long long)i * e_ld_t] = (unsigned char)((unsigned)w >> (8 * i));
+      return;
+    }
+    half_t* o = e_out_t + ((long long)b * ntr + (n - e_n_tr_begin)) * e_ld_t + tok;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[(long long)i * e_ld_t] = (half_t)v[i];
+    return;
+  }
+  if (e_k8 && n >= e_k8_begin && n < e_k8_end) {   // K columns of a fused q|k|v projection as e4m3 bytes
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    *reinterpret_cast<int*>(e_k8 + (long long)m * e_ld_k8 + (n - e_k8_begin)) = w;
+    return;
+  }
+  if (g.res) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    if (e_res_lo) {  // second term of the two-term residual stream: the chain value is res + res_lo
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+    }
+  }
+  if (g.out_f32) {
+    *reinterpret_cast<f4*>(reinterpret_cast<float*>(g.out) + (long long)m * g.ld_out + n) = v;
+  } else {
+    h4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+    *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
+    if (e_out_lo) {  // what the fp16 store dropped, for the next link of the residual chain
+      h4 l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[i] = (half_t)(v[i] - (float)o[i]);
+      *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
+    }
+  }
+}
+
+// Store 4 consecutive output columns n..n+3 of row m (b = m / tokens precomputed): one memory round trip, then the stores.
+__device__ __forceinline__ void epi_store4(const IgemmArgs& g, MD_LATE_PARAMS, int m, int b, int n, f4 v) {
+  f4 bv;
+  h4 rv, rl;
+  epi_load(g, MD_LATE_ARGS, m, b, n, bv, rv, rl);
+  epi_finish(g, MD_LATE_ARGS, m, b, n, v, bv, rv, rl);
+}
+
+// byte offset of W row n (k-tile 0): row-major [N][K], or the tiled form [N / 16][K / 64][16][64] -- 16 rows x 128 bytes of one
+// k-tile are one contiguous 2 KiB block and a 16-row panel's k-tiles follow each other IN THE ORDER THE KERNEL CONSUMES THEM (3x3:
+// channel block outer, tap inner), so a workgroup's weight stream is BN / 16 sequential streams instead of BN x 128-byte pieces
+// K * 2 bytes apart (one DRAM page each)
+__device__ __forceinline__ unsigned w_row_offset(int n, const IgemmArgs& g) {
+  return g.w_tiled ? (unsigned)(n >> 4) * (unsigned)g.nk * 2048u + (unsigned)(n & 15) * 128u : (unsigned)n * (unsigned)g.K * 2u;
+}
+
+// 16-lane (one DPP row = the 16 lr lanes that share lg) sum, fixed order -> deterministic: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror.  Every lane of the row ends up with the row's sum.
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+#endif
+  return v;
+}
+
+// The epilogue of one output tile.  acc: this wave's fp32 fragments ([n fragment][m fragment], D[n][m] layout: a lane owns 4
+// consecutive n of row lr); ln_sum / ln_sq: per-lane partial row statistics (LN only).  smem: the workgroup's LDS (>= LDS_TOTAL
+// bytes, free for reuse once every wave has passed the first barrier in here); tid = thread within its k-group.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool LN, int KG, int LDS_TOTAL>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const smem, f4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16],
+                                               [[maybe_unused]] float (&ln_sum)[BM / WAVES_M / 16],
+                                               [[maybe_unused]] float (&ln_sq)[BM / WAVES_M / 16], const int tid, const int kg,
+                                               const int wm, const int wn, const int m0, const int n0, const int Mlim, const int kz,
+                                               [[maybe_unused]] const float* const gbias,
+                                               [[maybe_unused]] const float* const gln_s1,
+                                               [[maybe_unused]] const float* const gln_s0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  static_assert((KG - 1) * NF * MF * 4096 + (LN ? (KG - 1) * MF * 2 * 1024 : 0) <= LDS_TOTAL, "cross-group reduction fits the stage memory");
+  const int lane = tid & 63;
+  const int lr = lane & 15, lg = lane >> 4;
+  // ---- k-groups: fixed-order sum of the groups' accumulators (and LayerNorm row sums) through LDS ------------------------------
+  if constexpr (KG > 1) {
+    __syncthreads();   // every group is done reading its stages
+    f4* const red = reinterpret_cast<f4*>(smem);
+    float* const red_ln = reinterpret_cast<float*>(smem + (KG - 1) * NF * MF * 4096);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) red[((kg - 1) * NF * MF + i * MF + j) * 256 + tid] = acc[i][j];
+      if constexpr (LN) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          red_ln[((kg - 1) * MF * 2 + 2 * j) * 256 + tid] = ln_sum[j];
+          red_ln[((kg - 1) * MF * 2 + 2 * j + 1) * 256 + tid] = ln_sq[j];
+        }
+      }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int q = 1; q < KG; ++q) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int j = 0; j < MF; ++j) acc[i][j] += red[((q - 1) * NF * MF + i * MF + j) * 256 + tid];
+        if constexpr (LN) {
+#pragma unroll
+          for (int j = 0; j < MF; ++j) {
+            ln_sum[j] += red_ln[((q - 1) * MF * 2 + 2 * j) * 256 + tid];
+            ln_sq[j] += red_ln[((q - 1) * MF * 2 + 2 * j + 1) * 256 + tid];
+          }
+        }
+      }
+    }
+  }
+  const bool epi = kg == 0;   // the epilogue belongs to group 0; the other groups only keep the (uniform) barriers below company
+
+  // ---- epilogue ---------------------------------------------------------------------------------------
+  const __attribute__((address_space(4))) IgemmArgs* gp = (const __attribute__((address_space(4))) IgemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(gp));   // opaque: the loads below cannot move above the k-loop
+  MD_LATE_LOAD(*gp)
+  float* const e_part = gp->part;
+  if (!epi && !e_part && !g.epi_stage) return;
+  if constexpr (LN) {
+    // row statistics over the full K (the launcher forbids split-K here), then acc <- rstd (acc - mu s1[n]) + s0[n]:
+    // LayerNorm(x) W^T + b with gamma folded into W, s1[n] = sum_k gamma_k W[n][k], s0[n] = sum_k beta_k W[n][k] + b[n]
+    if (epi) {
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+        float sm = ln_sum[j], sq = ln_sq[j];
+        sm += __shfl_xor(sm, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float mu = sm * g.ln_inv_k;
+        const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_k - mu * mu, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int n = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4);
+          const f4 s1 = *reinterpret_cast<const f4*>(gln_s1 + n), s0 = *reinterpret_cast<const f4*>(gln_s0 + n);
+          acc[i][j] = rstd * (acc[i][j] - mu * s1) + s0;
+        }
+      }
+    }
+  }
+  if (g.splitk > 1) {
+    if (!epi) return;
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + lr;
+      if (m >= Mlim) continue;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int n = n0 + wn * WTN + i * 16 + lg * 4;
+        if (n >= g.N) continue;
+        *reinterpret_cast<f4*>(g.ws + ((long long)kz * g.M + m) * g.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+  if (g.act == MD_ACT_GEGLU && g.epi_stage) {
+    // GEGLU through LDS (see the staged epilogue below): a * gelu(gate) as fp16 in the fragment layout -> LDS -> whole-row 16-byte
+    // stores ([M][N / 2] output, BN / 2 columns per tile)
+    if constexpr (NF % 2 == 0) {
+      constexpr int SROWH = BN / 2 + 8;   // fp16 row stride (16-byte aligned rows)
+      constexpr int CHG = BN / 16;        // 16-byte pieces per tile row
+      constexpr int NT = 256 * KG;
+      constexpr int U = (BM * CHG + NT - 1) / NT;
+      static_assert(BM * SROWH * 2 <= LDS_TOTAL, "staged GEGLU tile fits the stage memory");
+      half_t* const stg = reinterpret_cast<half_t*>(smem);
+      __syncthreads();
+      if (epi) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+#pragma unroll
+          for (int i = 0; i < NF; i += 2) {
+            const int np = min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 20);
+            f4 av = acc[i][j], gv = acc[i + 1][j];
+            if (gbias) {
+              av += *reinterpret_cast<const f4*>(gbias + np);
+              gv += *reinterpret_cast<const f4*>(gbias + np + 16);
+            }
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
+            *reinterpret_cast<h4*>(stg + (wm * WTM + j * 16 + lr) * SROWH + (wn * WTN) / 2 + (i / 2) * 16 + lg * 4) = o;
+          }
+        }
+      }
+      __syncthreads();
+      half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+      const int nh = g.N >> 1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = (int)threadIdx.x + NT * u;
+        const int r = c / CHG, cc = c - r * CHG;
+        const int m = m0 + r, oc = (n0 >> 1) + cc * 8;
+        if (c >= BM * CHG || m >= Mlim || oc >= nh) continue;
+        *reinterpret_cast<h8*>(outp + (long long)m * g.ld_out + oc) = *reinterpret_cast<const h8*>(stg + r * SROWH + cc * 8);
+      }
+    }
+    return;
+  }
+  if (g.act == MD_ACT_GEGLU) {
+    if (!epi) return;
+    if constexpr (NF % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + lr;
+        if (m >= Mlim) continue;
+#pragma unroll
+        for (int i = 0; i < NF; i += 2) {
+          const int np = n0 + wn * WTN + i * 16 + lg * 4;  // packed row of the "a" half; gate rows are +16
+          if (np + 16 >= g.N) continue;
+          f4 av = acc[i][j], gv = acc[i + 1][j];
+          if (gbias) {
+            av += *reinterpret_cast<const f4*>(gbias + np);
+            gv += *reinterpret_cast<const f4*>(gbias + np + 16);
+          }
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(av[r] * md::gelu_erf_f(gv[r]));
+          const int oc = (n0 + wn * WTN) / 2 + (i / 2) * 16 + lg * 4;
+          *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + oc) = o;
+        }
+      }
+    }
+    return;
+  }
+  if (g.epi_stage) {
+    // LDS-staged epilogue (round 3).  In the fragment layout a lane owns 4 consecutive columns of 16 DIFFERENT rows: every
+    // residual load / output store instruction of a wave is 64 x 8 bytes spread over 16 rows (32-byte pieces of 16 cache lines),
+    // and a 128 x 160 tile with the two-term residual stream needs 80 such instructions per lane -- on the short-K GEMMs (a
+    // 5-tile k-loop per output tile) the vector-memory ISSUE of the epilogue, not the MFMAs, the L2 or HBM, bounded the kernel.
+    // Here phase 1 parks bias + activation (fp32, fragment layout) in the stage memory, phase 2 walks the tile row-major: a
+    // thread owns 8 consecutive columns of one row = ONE 16-byte load per residual term and ONE 16-byte store per output term,
+    // consecutive lanes on consecutive 16-byte pieces of a row (whole 128-byte lines per instruction).
+    constexpr int SROW = BN + 4;                  // fp32 row stride: +4 keeps the 16 lanes of a DPP row on distinct banks
+    constexpr int ROUNDS = (BM * SROW * 4 <= LDS_TOTAL) ? 1 : 2;
+    static_assert(ROUNDS == 1 || (WAVES_M % 2 == 0 && (BM / 2) * SROW * 4 <= LDS_TOTAL), "staged epilogue fits the stage memory");
+    constexpr int RR = BM / ROUNDS;               // tile rows per round
+    constexpr int WPR = WAVES_M / ROUNDS;         // wave rows per round
+    constexpr int CH = BN / 8;                    // 16-byte output pieces per tile row
+    constexpr int NT = 256 * KG;
+    constexpr int U = (RR * CH + NT - 1) / NT;
+    float* const stg = reinterpret_cast<float*>(smem);
+    const float* __restrict__ const bp = gbias;
+    const half_t* __restrict__ const resp = g.res;
+    const half_t* __restrict__ const rlp = e_res_lo;
+    half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+    half_t* __restrict__ const olp = e_out_lo;
+    const int tall = (int)threadIdx.x;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      __syncthreads();   // the stage memory is free: k-loop reads (rd = 0) / the previous round's phase 2 are done
+      if (epi && wm / WPR == rd) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          const int m = m0 + wm * WTM + j * 16 + lr;
+          const int b = fast_div(min(m, Mlim - 1), g.div_tok_mul, g.div_tok_sh);
+          f4 bv[NF];
+#pragma unroll
+          for (int i = 0; i < NF; ++i) bv[i] = f4{0.f, 0.f, 0.f, 0.f};
+          if (bp) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          }
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            f4 v = acc[i][j] + bv[i];
+            if (n0 + wn * WTN + i * 16 + lg * 4 < e_col_scale_end) v *= e_col_scale;
+            if (g.act == MD_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+            }
+            *reinterpret_cast<f4*>(stg + ((wm % WPR) * WTM + j * 16 + lr) * SROW + wn * WTN + i * 16 + lg * 4) = v;
+          }
+        }
+      }
+      // phase 2 in batches of UB pieces per thread (register budget: all of a 128 x 160 tile's 5 pieces in flight cost a wave
+      // per SIMD); the first batch's residual loads do not depend on phase 1 and are in flight across the barrier
+      constexpr int UB = U < 3 ? U : 3;
+#pragma unroll
+      for (int u0 = 0; u0 < U; u0 += UB) {
+        h8 rv[UB], rl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int c = tall + NT * (u0 + u);
+          const int r = c / CH, cc = c - r * CH;
+          const int mc = min(m0 + rd * RR + r, Mlim - 1), nc = min(n0 + cc * 8, g.N - 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[u][e] = (half_t)0.f;
+          rl[u] = rv[u];
+          if (u0 + u < U && resp) {
+            rv[u] = *reinterpret_cast<const h8*>(resp + (long long)mc * g.ld_res + nc);
+            if (rlp) rl[u] = *reinterpret_cast<const h8*>(rlp + (long long)mc * g.ld_res + nc);
+          }
+        }
+        if (u0 == 0) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (u0 + u >= U) continue;
+          const int c = tall + NT * (u0 + u);
+          const int r = c / CH, cc = c - r * CH;
+          const int m = m0 + rd * RR + r, n = n0 + cc * 8;
+          if (c >= RR * CH || m >= Mlim || n >= g.N) continue;
+          const float* sp = stg + r * SROW + cc * 8;
+          const f4 v0 = *reinterpret_cast<const f4*>(sp), v1 = *reinterpret_cast<const f4*>(sp + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          h8 o, l;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] += (float)rv[u][e];
+            v[e] += (float)rl[u][e];
+            o[e] = (half_t)v[e];
+            l[e] = (half_t)(v[e] - (float)o[e]);
+          }
+          *reinterpret_cast<h8*>(outp + (long long)m * g.ld_out + n) = o;
+          if (olp) *reinterpret_cast<h8*>(olp + (long long)m * g.ld_out + n) = l;
+        }
+      }
+    }
+    return;
+  }
+  if (!g.out_f32 && e_n_tr_begin >= g.N && !e_k8) {
+    // Common case (fp16 row-major output: every conv, the attention / feed-forward output projections, proj_in / proj_out): the
+    // loads of a whole column of fragments -- bias, residual, second residual term -- are issued together, on clamped addresses,
+    // before any is consumed.  (Fragment by fragment through epi_store4 the compiler emits load -> s_waitcnt vmcnt(0) -> store
+    // chains: 3 x NF x MF serial memory round trips per wave, more than the k-loop of a 5-tile GEMM.)
+    const bool has_bias = gbias != nullptr;
+    // restrict: `res` / `res_lo` are either disjoint from `out` / `out_lo` or IDENTICAL to them (in-place residual add: a lane
+    // reads exactly the elements it then writes, ordered by the data dependence) -- never partially overlapping (header contract).
+    // (Measured and dropped, same-box A/B in profiles/round2_igemm_epilogue_ab.txt: two columns in flight with unconditional
+    //  zero-page loads for absent operands -- 3-8 % slower on the epilogue-dominated GEMMs, end to end -0.4 %.)
+    const float* __restrict__ const bp = gbias;
+    const half_t* __restrict__ const resp = g.res;
+    const half_t* __restrict__ const rlp = e_res_lo;
+    half_t* __restrict__ const outp = reinterpret_cast<half_t*>(g.out);
+    half_t* __restrict__ const olp = e_out_lo;
+    // GroupNorm partials: per 16-row fragment the lanes' values are summed over the fragment's rows at once (DPP, fixed order) and
+    // parked in LDS [wave row][fragment][column][sum | sumsq] -- nothing is carried in registers across fragments (accumulating in
+    // registers cost 40 VGPRs and a wave per SIMD of occupancy on the 160-wide tiles, whether or not partials were requested)
+    float* const pred = reinterpret_cast<float*>(smem);
+    if (e_part) __syncthreads();   // every wave is done with the k-loop's (and the k-group reduction's) LDS reads
+    if (epi) {
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + lr;
+        const int mc = min(m, Mlim - 1);
+        const int b = fast_div(mc, g.div_tok_mul, g.div_tok_sh);
+        f4 bv[NF];
+        h4 rv[NF], rl[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          bv[i] = f4{0.f, 0.f, 0.f, 0.f};
+          rv[i] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          rl[i] = rv[i];
+        }
+        if (has_bias) {   // (bias_bs == 0: the same vector for every row -- served by L1)
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            bv[i] = *reinterpret_cast<const f4*>(bp + (long long)b * g.bias_bs + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+        }
+        if (resp) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            rv[i] = *reinterpret_cast<const h4*>(resp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          if (rlp) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              rl[i] = *reinterpret_cast<const h4*>(rlp + (long long)mc * g.ld_res + min(n0 + wn * WTN + i * 16 + lg * 4, g.N - 4));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool row_ok = m < Mlim;
+        if (!row_ok && !e_part) continue;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int n = n0 + wn * WTN + i * 16 + lg * 4;
+          if (n >= g.N) continue;   // (uniform over the 16 lanes of a DPP row: they share lg)
+          f4 v = acc[i][j];
+          v += bv[i];
+          if (n < e_col_scale_end) v *= e_col_scale;
+          if (g.act == MD_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = md::silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[i][e];   // (zeros when there is no residual / no second term)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rl[i][e];
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          if (row_ok) {
+            *reinterpret_cast<h4*>(outp + (long long)m * g.ld_out + n) = o;
+            if (olp) {
+              h4 l;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) l[e] = (half_t)(v[e] - (float)o[e]);
+              *reinterpret_cast<h4*>(olp + (long long)m * g.ld_out + n) = l;
+            }
+          }
+          if (e_part) {   // statistics of the value the GroupNorm will read: the rounded fp16 hi term (rows past the end: 0)
+            float sv[4], qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f = row_ok ? (float)o[e] : 0.f;
+              sv[e] = row16_sum(f);
+              qv[e] = row16_sum(f * f);
+            }
+            if (lr == 0) {
+              float* d = pred + (((wm * MF + j) * BN) + wn * WTN + i * 16 + lg * 4) * 2;
+              *reinterpret_cast<f4*>(d) = f4{sv[0], qv[0], sv[1], qv[1]};
+              *reinterpret_cast<f4*>(d + 4) = f4{sv[2], qv[2], sv[3], qv[3]};
+            }
+          }
+        }
+      }
+    }
+    if (e_part) {
+      __syncthreads();
+      if (epi && tid < BN && n0 + tid < g.N) {   // per 64-row granule and column: wave rows, then fragments, in fixed order
+        constexpr int WPG = 64 / WTM > WAVES_M ? WAVES_M : 64 / WTM;   // wave rows per granule
+#pragma unroll
+        for (int gi = 0; gi < (BM + 63) / 64; ++gi) {
+          if (m0 + gi * 64 >= Mlim) break;
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WPG; ++w2)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+              s += pred[(((gi * WPG + w2) * MF + j) * BN + tid) * 2];
+              q += pred[(((gi * WPG + w2) * MF + j) * BN + tid) * 2 + 1];
+            }
+          float* dst = e_part + ((long long)(m0 / 64 + gi) * 2) * g.N + n0 + tid;
+          dst[0] = s;
+          dst[g.N] = q;
+        }
+      }
+    }
+    return;
+  }
+  if (!epi) return;
+#pragma unroll
+  for (int j = 0; j < MF; ++j) {
+    const int m = m0 + wm * WTM + j * 16 + lr;
+    if (m >= Mlim) continue;
+    const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + lg * 4;
+      if (n >= g.N) continue;
+      epi_store4(g, MD_LATE_ARGS, m, b, n, acc[i][j]);
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+
+// ---- the ring form (igemm_ring.hip): tile configs 40.. -----------------------------------------------------------------------
+struct RingCfg {
+  int bm, bn, wm, wn, kt, kg, d1, d9;   // tile, waves, k-tiles per group and step, k-groups, ring slots for 1x1 / 3x3 layers
+};
+constexpr int kFirstRingCfg = 40;
+int ring_num_cfgs();
+const RingCfg* ring_cfg(int cfg);                       // nullptr: no such config
+long long ring_lds_bytes(int cfg, int ksize, int win);  // dynamic LDS of a launch (<= 160 KiB or the launch is refused)
+int igemm_ring_launch(const IgemmArgs& g, int cfg, hipStream_t s);
+
+}  // namespace mdig

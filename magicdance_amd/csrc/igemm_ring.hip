@@ -1,0 +1,432 @@
+// md_igemm, ring form (round 4): the k-loop of igemm.hip re-built as a MULTI-SLOT LDS RING with counted waits, for the layers
+// whose time is operand latency, not MFMA work -- above all the 8x8 / 16x16 levels of a one-frame DDIM step (M <= 1024), which
+// stream 3-60 MB of cold weights per launch through a few hundred output tiles.
+//
+// What differs from the 2-stage loop (igemm.hip):
+//   * D ring slots instead of 2 stages.  A step (KG x KT k-tiles) is computed while the D - 1 following steps are in flight; the
+//     wait in front of a step is `s_waitcnt vmcnt(n)` with n = the number of this wave's loads issued AFTER the step's own loads
+//     (tracked exactly in scalar registers: every wave counts the LDS-DMA instructions it issues), never a drain.  One raw
+//     `s_barrier` per step; no `__syncthreads()` inside the loop (hipcc's carries a vmcnt(0) while LDS-DMA is in flight).
+//   * Every LDS-DMA instruction reads IN-RANGE addresses (rows past the end are clamped to the last row and never stored) --
+//     counted waits rely on in-order completion, which the hardware out-of-range path of the 2-stage loader's padding taps does
+//     not guarantee (see attention.hip).  Hence:
+//   * 3x3 convs (stride 1, no upsample) do not gather nine shifted copies of the activations.  Per 64-channel block ONE "A block"
+//     -- the tile's BM pixels plus a halo of win + 1 pixels on either side, [rows][64 ch], each row loaded once -- sits in LDS for
+//     all nine taps; tap (dy, dx) of output pixel m reads block row (m - m0) + dy * win + dx, and padding taps read a zero row
+//     (per-lane 9-bit validity masks, computed once).  L2 -> LDS activation traffic drops by BM * 9 / (BM + 2 win + 2): 4.4x at the
+//     64 x 64 level, 7.9x at 8 x 8 -- what remains of the k-loop's vector-memory traffic is the weight stream itself.
+//   * all 4 KG waves of a workgroup load every tile cooperatively (wave w issues the 8-row pieces w, w + 4 KG, ...).
+// Same tile mapping (XCD-aware grouped raster, second parameter set, split-K over blockIdx.z in units of whole channel blocks),
+// same MFMA fragment layout and the same epilogue (igemm_core.h) as the 2-stage kernels.
+//
+// Reference arithmetic replaced: see include/magicdance_hip.h (md_igemm).
+#include "igemm_core.h"
+
+namespace mdig {
+namespace {
+
+// s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier -- n is wave-uniform and only known at run time; the count field is an immediate.
+// A smaller count than asked for is merely stricter, so n > 40 waits for 40.
+__device__ __forceinline__ void ring_wait_barrier(int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  n = n < 0 ? 0 : n;
+#define MD_RW(k)                                                                     \
+  case k:                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    break;
+  switch (n) {
+    MD_RW(0) MD_RW(1) MD_RW(2) MD_RW(3) MD_RW(4) MD_RW(5) MD_RW(6) MD_RW(7) MD_RW(8) MD_RW(9)
+    MD_RW(10) MD_RW(11) MD_RW(12) MD_RW(13) MD_RW(14) MD_RW(15) MD_RW(16) MD_RW(17) MD_RW(18) MD_RW(19)
+    MD_RW(20) MD_RW(21) MD_RW(22) MD_RW(23) MD_RW(24) MD_RW(25) MD_RW(26) MD_RW(27) MD_RW(28) MD_RW(29)
+    MD_RW(30) MD_RW(31) MD_RW(32) MD_RW(33) MD_RW(34) MD_RW(35) MD_RW(36) MD_RW(37) MD_RW(38) MD_RW(39)
+    default:
+      asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef MD_RW
+#endif
+}
+
+// n / 9 for 0 <= n < 74898 (k-tile index -> channel block; uniform, scalar)
+__device__ __forceinline__ int div9(int n) { return (int)(((unsigned)n * 58255u) >> 19); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KT, int D, int KG, int TAPS, bool LN>
+__global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(TAPS == 1 || TAPS == 9, "1x1 / linear layers and 3x3 convs");
+  static_assert(!LN || TAPS == 1, "LayerNorm folding belongs to the linear layers");
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per k-group");
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  constexpr int NW = 4 * KG;            // waves per workgroup: all of them load every tile
+  constexpr int TS = KG * KT;           // k-tiles per step (one ring slot)
+  constexpr int TILE_W = BN * 128, TILE_A = BM * 128;
+  constexpr int SLOT_W = TS * TILE_W, SLOT_A = TAPS == 1 ? TS * TILE_A : 0;
+  constexpr int RING_BYTES = D * (SLOT_W + SLOT_A);   // (3x3: + two A blocks + the zero row, sized at run time)
+  constexpr int RBW = BN / 8, RBA = BM / 8;           // 8-row (1 KiB) pieces per tile
+  constexpr int WJ = (RBW + NW - 1) / NW, AJ = (RBA + NW - 1) / NW;
+  static_assert(BM % 32 == 0 && BN % 16 == 0 && WTM <= 64, "tile shape");
+  static_assert(D >= 2 && D <= 12 && TS <= 8, "ring depth; a step never reaches beyond the next channel block");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x & 255;   // thread within its k-group
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave within the workgroup (loader role)
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+  // ---- tile of this workgroup: same mapping as igemm.hip --------------------------------------------------------------------
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8g = nwg & 7;
+  const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
+  const int per_group = g.group_m * g.tiles_n;
+  const int grp = logical / per_group, in_grp = logical - grp * per_group;
+  const int first_m = grp * g.group_m;
+  const int gsz = min(g.tiles_m - first_m, g.group_m);
+  const int tile_n = in_grp / gsz, tile_m = first_m + (in_grp - tile_n * gsz);
+  const bool set2 = tile_m >= g.tiles_m1;
+  const int m0 = set2 ? g.m_split + (tile_m - g.tiles_m1) * BM : tile_m * BM;
+  const int Mlim = set2 ? g.M : min(g.M, g.m_split);
+  const int n0 = tile_n * BN;
+  const int kz = blockIdx.z;
+  const int kt_begin = kz * g.tiles_per_split;            // (3x3: a multiple of 9 -- whole channel blocks)
+  const int kt_end = min(g.nk, kt_begin + g.tiles_per_split);
+  const int nsteps = kt_begin < kt_end ? (kt_end - kt_begin + TS - 1) / TS : 0;
+  const half_t* const gw = set2 ? g.w2 : g.w;
+  [[maybe_unused]] const float* const gbias = set2 ? g.bias2 : g.bias;
+  [[maybe_unused]] const float* const gln_s1 = set2 ? g.ln2_s1 : g.ln_s1;
+  [[maybe_unused]] const float* const gln_s0 = set2 ? g.ln2_s0 : g.ln_s0;
+
+  // ---- loader role ------------------------------------------------------------------------------------------------------------
+  // one LDS-DMA instruction = 8 rows x 128 B: lane (r8, c8) lands at row r8, 16-byte position c8 and fetches source chunk c8 ^ r8
+  // (the XOR swizzle lives on the source side; the fragment reads below apply the same involution)
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const unsigned gcb = (unsigned)(c8 ^ r8) * 16u;
+  const int mtot = g.batch * g.hin * g.win;   // source pixels (stride 1: = M)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.a0), 0, mtot * g.c0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.a1 ? g.a1 : g.a0), 0, mtot * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
+  unsigned w_off[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) w_off[j] = w_row_offset(min(n0 + (wv + NW * j) * 8 + r8, g.N - 1), g) + gcb;
+  [[maybe_unused]] unsigned ra0[AJ], ra1[AJ];
+  if constexpr (TAPS == 1) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const unsigned m = (unsigned)min(m0 + (wv + NW * j) * 8 + r8, Mlim - 1);   // rows past the end: clamped, never stored
+      ra0[j] = m * (unsigned)g.c0 * 2u + gcb;
+      ra1[j] = m * (unsigned)g.c1 * 2u + gcb;
+    }
+  }
+  // 3x3: A block geometry (g.ring_a_rows = BM + 2 win + 2 rounded up to 8 rows)
+  [[maybe_unused]] const int a_slot_bytes = g.ring_a_rows * 128;
+  [[maybe_unused]] const int a_pieces = g.ring_a_rows >> 3;
+  [[maybe_unused]] const int p_lo = m0 - (g.win + 1);                 // source pixel of block row 0
+  [[maybe_unused]] const int zero_off = RING_BYTES + 2 * a_slot_bytes;   // 128 zero bytes: what a padding tap reads
+
+  int tot = 0;   // this wave's LDS-DMA instructions issued so far (the vmcnt sequence number of the youngest)
+
+  auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+    ++tot;
+  };
+  auto issue_w_tile = [&](char* dst, int kt) {
+    unsigned ksoff;
+    if (g.w_tiled) {
+      ksoff = (unsigned)kt * 2048u;   // the k-tiles of a 16-row panel are stored in consumption order
+    } else if constexpr (TAPS == 9) {
+      const int cb = div9(kt), tap = kt - 9 * cb;
+      ksoff = (unsigned)(tap * g.cin + cb * 64) * 2u;
+    } else {
+      ksoff = (unsigned)kt * 128u;
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int q = wv + NW * j;   // (wave-uniform)
+      if (RBW % NW == 0 || q < RBW) dma(rs_w, dst + q * 1024, w_off[j], ksoff);
+    }
+  };
+  auto issue_a_tile = [&](char* dst, int kt) {   // 1x1: the tile's BM rows x 64 channels of k-tile kt
+    const int cc = kt * 64;
+    const bool second = cc >= g.c0;
+    const unsigned soff = (unsigned)(second ? cc - g.c0 : cc) * 2u;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int q = wv + NW * j;
+      if (RBA % NW == 0 || q < RBA) {
+        if (second)
+          dma(rs_a1, dst + q * 1024, ra1[j], soff);
+        else
+          dma(rs_a0, dst + q * 1024, ra0[j], soff);
+      }
+    }
+  };
+  auto issue_a_block = [&](int cb) {   // 3x3: pixels p_lo .. p_lo + ring_a_rows - 1 (clamped into the tensor) x channel block cb
+    const int cc = cb * 64;
+    const bool second = cc >= g.c0;
+    const unsigned cs2 = (unsigned)(second ? g.c1 : g.c0) * 2u;
+    const unsigned soff = (unsigned)(second ? cc - g.c0 : cc) * 2u;
+    char* const dst = smem + RING_BYTES + (cb & 1) * a_slot_bytes;
+    for (int q = wv; q < a_pieces; q += NW) {
+      const int p = min(max(p_lo + q * 8 + r8, 0), mtot - 1);
+      const unsigned vo = (unsigned)p * cs2 + gcb;
+      if (second)
+        dma(rs_a1, dst + q * 1024, vo, soff);
+      else
+        dma(rs_a0, dst + q * 1024, vo, soff);
+    }
+  };
+  auto issue_step = [&](int s, int slot) {   // every load of compute step s, into ring slot ``slot``
+    char* const ws = smem + slot * SLOT_W;
+    [[maybe_unused]] char* const as = smem + D * SLOT_W + slot * SLOT_A;
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int kt = kt_begin + s * TS + t;
+      if (kt < kt_end) {
+        issue_w_tile(ws + t * TILE_W, kt);
+        if constexpr (TAPS == 1) issue_a_tile(as + t * TILE_A, kt);
+      }
+    }
+  };
+
+  // ---- prologue: fill D - 1 slots (and the first A block) before anything else ----------------------------------------------------
+  [[maybe_unused]] int aseq0 = 0, aseq1 = 0;   // sequence number of the last load of the A block in slot 0 / 1
+  [[maybe_unused]] const int cb_begin = div9(kt_begin), cb_end = div9(kt_end + 8);
+  [[maybe_unused]] int a_issued = cb_begin;
+  if constexpr (TAPS == 9) {
+    if (threadIdx.x < 8) *reinterpret_cast<f4*>(smem + zero_off + threadIdx.x * 16) = f4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) {
+      issue_a_block(cb_begin);
+      if (cb_begin & 1)
+        aseq1 = tot;
+      else
+        aseq0 = tot;
+    }
+  }
+  int wq[D - 1];   // wq[i]: sequence number of the last load of compute step (current + i)
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i) {
+    if (i < nsteps) issue_step(i, i);
+    wq[i] = tot;
+  }
+
+  // ---- compute role -------------------------------------------------------------------------------------------------------------
+  // 3x3: per m-fragment the 9-bit mask of taps that fall inside the image for this lane's output pixel
+  [[maybe_unused]] int amask[MF];
+  if constexpr (TAPS == 9) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      const int m = min(m0 + wm * WTM + i * 16 + lr, Mlim - 1);
+      const int b = fast_div(m, g.div_tok_mul, g.div_tok_sh);
+      const int rem = m - b * g.tokens;
+      const int oy = fast_div(rem, g.div_w_mul, g.div_w_sh);
+      const int ox = rem - oy * g.wout;
+      int cx = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) cx |= ((unsigned)(ox + d - 1) < (unsigned)g.win) ? (1 << d) : 0;
+      int mask = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) mask |= ((unsigned)(oy + d - 1) < (unsigned)g.hin) ? (cx << (3 * d)) : 0;
+      amask[i] = mask;
+    }
+  }
+
+  f4 acc[NF][MF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float ln_sum[MF], ln_sq[MF];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
+  }
+
+  // one k-tile: all operand fragments requested from LDS, then the MFMAs (two 32-deep k-steps)
+  auto compute_tile = [&](const char* Wt, [[maybe_unused]] const char* At, [[maybe_unused]] int kt) {
+    h8 af[2][MF], wf[2][NF];
+    if constexpr (TAPS == 9) {
+      const int cb = div9(kt), tap = kt - 9 * cb;
+      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+      const int tapoff = dy * g.win + dx;                              // block row of this tap = (m - m0) + tapoff
+      const int ablk = RING_BYTES + (cb & 1) * a_slot_bytes;
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int row = wm * WTM + i * 16 + lr + tapoff;
+        int off = ablk + row * 128 + ((lg ^ (row & 7)) << 4);
+        off = ((amask[i] >> tap) & 1) ? off : zero_off;
+        af[0][i] = *reinterpret_cast<const h8*>(smem + off);
+        af[1][i] = *reinterpret_cast<const h8*>(smem + (off ^ 64));   // chunk 4 + lg of the same row (the zero row is 128 bytes)
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int row = wm * WTM + i * 16 + lr;
+          af[ks][i] = *reinterpret_cast<const h8*>(At + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int row = wn * WTN + i * 16 + lr;
+        wf[ks][i] = *reinterpret_cast<const h8*>(Wt + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (LN) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
+            ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
+            ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- the ring -------------------------------------------------------------------------------------------------------------------
+  int cslot = 0, islot = D - 1;   // slot of the step being computed / of the step issued next (= the slot freed by the barrier)
+  for (int s = 0; s < nsteps; ++s) {
+    int need = wq[0];
+#pragma unroll
+    for (int i = 0; i + 1 < D - 1; ++i) wq[i] = wq[i + 1];
+    if constexpr (TAPS == 9) {   // the A block(s) of this step: the younger one covers the older (in-order completion)
+      const int cbl = div9(min(kt_begin + s * TS + TS - 1, kt_end - 1));
+      need = max(need, (cbl & 1) ? aseq1 : aseq0);
+    }
+    // this wave's loads of step s have landed; every wave's reads of step s - 1 are done -> the barrier publishes step s and
+    // frees slot (s - 1) % D (and, 3x3, every A block before the one step s starts in)
+    ring_wait_barrier(tot - need);
+    if constexpr (TAPS == 9) {
+      const int cbmin = div9(kt_begin + s * TS);
+      if (a_issued <= cbmin && cbmin + 1 < cb_end) {
+        issue_a_block(cbmin + 1);
+        a_issued = cbmin + 1;
+        if (a_issued & 1)
+          aseq1 = tot;
+        else
+          aseq0 = tot;
+      }
+    }
+    if (s + D - 1 < nsteps) issue_step(s + D - 1, islot);
+    wq[D - 2] = tot;
+    islot = islot + 1 == D ? 0 : islot + 1;
+    const char* const ws = smem + cslot * SLOT_W;
+    [[maybe_unused]] const char* const as = smem + D * SLOT_W + cslot * SLOT_A;
+    cslot = cslot + 1 == D ? 0 : cslot + 1;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int t = u * KG + kg;
+      const int kt = kt_begin + s * TS + t;
+      if (kt < kt_end) compute_tile(ws + t * TILE_W, as + t * TILE_A, kt);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is outstanding here; keeps the epilogue's LDS reuse independent of that)
+
+  igemm_epilogue<BM, BN, WAVES_M, WAVES_N, LN, KG, RING_BYTES>(g, smem, acc, ln_sum, ln_sq, tid, kg, wm, wn, m0, n0, Mlim, kz, gbias, gln_s1,
+                                                               gln_s0);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// Ring tile configs (ids kFirstRingCfg + index; igemm_tuned.inc refers to them).  d1 / d9: ring slots for 1x1 / 3x3 layers, sized
+// so that a 1x1 launch uses <= 144 KiB and a 3x3 launch leaves room for its two A blocks.
+const RingCfg kRing[] = {
+    {64, 64, 2, 2, 1, 1, 8, 10},    // 40
+    {64, 64, 2, 2, 2, 1, 4, 6},     // 41
+    {64, 64, 2, 2, 1, 2, 4, 6},     // 42
+    {64, 80, 4, 1, 1, 1, 8, 9},     // 43
+    {64, 80, 4, 1, 1, 2, 4, 5},     // 44
+    {128, 64, 2, 2, 1, 1, 6, 10},   // 45
+    {128, 64, 2, 2, 1, 2, 3, 6},    // 46
+    {128, 80, 4, 1, 1, 1, 5, 8},    // 47
+    {128, 80, 4, 1, 1, 2, 3, 4},    // 48
+    {128, 160, 2, 2, 1, 1, 4, 4},   // 49
+    {128, 128, 2, 2, 1, 1, 4, 5},   // 50
+    {256, 64, 4, 1, 1, 1, 3, 10},   // 51
+    {64, 160, 2, 2, 1, 1, 5, 5},    // 52
+};
+constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
+
+template <int BM, int BN, int WMv, int WNv, int KT, int D, int KG, int TAPS, bool LN>
+int launch_ring_k(const IgemmArgs& g, hipStream_t s) {
+  constexpr int ring_bytes = D * KG * KT * (BN + (TAPS == 1 ? BM : 0)) * 128;
+  const size_t lds = (size_t)ring_bytes + (TAPS == 9 ? (size_t)2 * g.ring_a_rows * 128 + 128 : 0);
+  if (lds > 160 * 1024) return MD_ERR_UNSUPPORTED;
+  static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
+  int devi = 0;
+  MD_HIP_CHECK(hipGetDevice(&devi));
+  if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (devi >= 0 && devi < 64) attr_set[devi] = true;
+  }
+  dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN>), grid, dim3(256 * KG), lds, s, g);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+template <int BM, int BN, int WMv, int WNv, int KT, int KG, int D1, int D9>
+int launch_ring_t(const IgemmArgs& g, hipStream_t s) {
+  if (g.ksize == 3) return launch_ring_k<BM, BN, WMv, WNv, KT, D9, KG, 9, false>(g, s);
+  if (g.ln_s1) return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, true>(g, s);
+  return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, false>(g, s);
+}
+
+}  // namespace
+
+int ring_num_cfgs() { return kNumRing; }
+
+const RingCfg* ring_cfg(int cfg) {
+  const int i = cfg - kFirstRingCfg;
+  return (i >= 0 && i < kNumRing) ? &kRing[i] : nullptr;
+}
+
+long long ring_lds_bytes(int cfg, int ksize, int win) {
+  const RingCfg* c = ring_cfg(cfg);
+  if (!c) return -1;
+  if (ksize == 3) {
+    const long long a_rows = (c->bm + 2 * win + 2 + 7) & ~7;
+    return (long long)c->d9 * c->kg * c->kt * c->bn * 128 + 2 * a_rows * 128 + 128;
+  }
+  return (long long)c->d1 * c->kg * c->kt * (c->bn + c->bm) * 128;
+}
+
+// The launch of a ring config.  md_igemm (igemm.hip) has validated the layer for this form: buffer-loader channel counts, stride 1,
+// no upsample, symmetric padding, tiles_per_split a multiple of 9 for the 3x3 convs, ring_a_rows set.
+int igemm_ring_launch(const IgemmArgs& g, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 40: return launch_ring_t<64, 64, 2, 2, 1, 1, 8, 10>(g, s);
+    case 41: return launch_ring_t<64, 64, 2, 2, 2, 1, 4, 6>(g, s);
+    case 42: return launch_ring_t<64, 64, 2, 2, 1, 2, 4, 6>(g, s);
+    case 43: return launch_ring_t<64, 80, 4, 1, 1, 1, 8, 9>(g, s);
+    case 44: return launch_ring_t<64, 80, 4, 1, 1, 2, 4, 5>(g, s);
+    case 45: return launch_ring_t<128, 64, 2, 2, 1, 1, 6, 10>(g, s);
+    case 46: return launch_ring_t<128, 64, 2, 2, 1, 2, 3, 6>(g, s);
+    case 47: return launch_ring_t<128, 80, 4, 1, 1, 1, 5, 8>(g, s);
+    case 48: return launch_ring_t<128, 80, 4, 1, 1, 2, 3, 4>(g, s);
+    case 49: return launch_ring_t<128, 160, 2, 2, 1, 1, 4, 4>(g, s);
+    case 50: return launch_ring_t<128, 128, 2, 2, 1, 1, 4, 5>(g, s);
+    case 51: return launch_ring_t<256, 64, 4, 1, 1, 1, 3, 10>(g, s);
+    case 52: return launch_ring_t<64, 160, 2, 2, 1, 1, 5, 5>(g, s);
+    default: return MD_ERR_BAD_ARG;
+  }
+}
+
+}  // namespace mdig

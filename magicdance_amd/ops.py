@@ -83,6 +83,23 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     return out
 
 
+def igemm_config_info(cfg):
+    """md_igemm_config_info: dict(bm, bn, kt, kg, ring, d1, d9, wn) of tile config ``cfg``, or None when the id does not exist."""
+    info = (C.c_int32 * 8)()
+    if _lib.load().md_igemm_config_info(int(cfg), C.byref(info)) != _lib.MD_OK:
+        return None
+    return dict(bm=info[0], bn=info[1], kt=info[2], kg=info[3], ring=bool(info[4]), d1=info[5], d9=info[6], wn=info[7])
+
+
+def ring_lds_bytes(cfg, ksize, win):
+    """dynamic LDS a ring config needs for a layer (the launcher refuses > 160 KiB): mirrors igemm_ring.hip::ring_lds_bytes"""
+    c = igemm_config_info(cfg)
+    if ksize == 3:
+        a_rows = (c["bm"] + 2 * win + 2 + 7) & ~7
+        return c["d9"] * c["kg"] * c["kt"] * c["bn"] * 128 + 2 * a_rows * 128 + 128
+    return c["d1"] * c["kg"] * c["kt"] * (c["bn"] + c["bm"]) * 128
+
+
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
               k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False):
     lib = _lib.load()

@@ -1,0 +1,289 @@
+"""GPU parity of md_igemm's RING form (tile configs 40.., magicdance_amd/csrc/igemm_ring.hip) against plain PyTorch fp32 of the same
+op and, bit for bit, against itself (repeated launches: the counted waits of the ring must never let a tile be read before it
+landed) and against two launches on the two sample ranges (second parameter set).  Same conventions as test_gpu_kernels.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = torch.float16, torch.float32
+RING_CFGS = list(range(40, 53))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from magicdance_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _gen(seed):
+    return torch.Generator(device="cpu").manual_seed(seed)
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    return (torch.randn(shape, generator=_gen(seed)) * scale).to(dev)
+
+
+def _nhwc16(x):
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b, h * w, c).to(F16).contiguous()
+
+
+def _nchw32(t, b, h, w):
+    return t.float().reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def _err(a, b):
+    return float((a.float() - b.float()).abs().max())
+
+
+def _fits(cfg, ksize, win):
+    from magicdance_amd import ops
+    return ops.ring_lds_bytes(cfg, ksize, win) <= 160 * 1024
+
+
+def _igemm_or_refused(cfg, ksize, win, call):
+    """run ``call``; a config whose ring does not fit the LDS at this image width must be refused loudly instead"""
+    from magicdance_amd import _lib
+    if _fits(cfg, ksize, win):
+        call()
+        return True
+    with pytest.raises(_lib.MagicDanceHipError):
+        call()
+    return False
+
+
+def test_ring_config_table(dev):
+    from magicdance_amd import ops
+    for cfg in RING_CFGS:
+        c = ops.igemm_config_info(cfg)
+        assert c is not None and c["ring"] and c["kg"] in (1, 2) and c["kg"] * c["kt"] <= 4 and 2 <= c["d1"] <= 12 and 2 <= c["d9"] <= 12
+        assert ops.ring_lds_bytes(cfg, 1, 1) <= 160 * 1024          # every 1x1 launch fits
+        assert ops.ring_lds_bytes(cfg, 3, 8) <= 160 * 1024          # and the 8x8 level's 3x3 convs
+    assert ops.igemm_config_info(RING_CFGS[-1] + 1) is None and not ops.igemm_config_info(15)["ring"]
+
+
+CONV_CASES = [
+    # name, B, Cin(s), H, W, Cout, k
+    ("c3_16", 2, (64,), 16, 16, 96, 3),          # N = 96: tail of every tile width
+    ("c3_cat", 2, (64, 128), 8, 8, 128, 3),      # two sources (skip concat), 27 k-tiles
+    ("c1_cat", 1, (128, 64), 16, 16, 320, 1),
+    ("c3_32", 1, (320,), 32, 32, 320, 3),
+    ("c3_odd", 1, (64,), 7, 9, 64, 3),           # image width 9: halo rows, M = 63 (clamped rows)
+    ("c3_64", 1, (64,), 64, 64, 80, 3),          # the 64 x 64 level: a 130-pixel halo
+    ("c1_deep", 2, (1280,), 8, 8, 1280, 1),      # 20 k-tiles: the ring wraps
+    ("c3_deep", 3, (256,), 8, 8, 160, 3),        # 36 k-tiles, 4 channel blocks
+    ("c3_3img", 3, (128,), 16, 16, 128, 3),      # tiles that straddle sample boundaries
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("splitk,tiled", [(1, True), (1, False), (2, True), (3, True)])
+def test_ring_conv(dev, case, cfg, splitk, tiled):
+    from magicdance_amd import ops, engine
+    name, b, cins, h, w, cout, k = case
+    cin = sum(cins)
+    if splitk > 1 and (cin // 64) * (k * k) // splitk < 2:
+        pytest.skip("K too short for this split")
+    if tiled and cout % 16:
+        pytest.skip("tiled weights need N % 16 == 0")
+    xs = [_rand((b, c, h, w), 10 + i, dev) for i, c in enumerate(cins)]
+    wt = _rand((cout, cin, k, k), 20, dev, scale=(cin * k * k) ** -0.5)
+    bias = _rand((cout,), 21, dev, 0.1)
+    x16 = [_nhwc16(x) for x in xs]
+    w16 = engine.pack_conv(wt, dev)
+    if tiled:
+        w16 = ops.tile_weights(w16, k)
+    ref = F.conv2d(torch.cat([x.half().float() for x in xs], 1), wt.half().float(), bias, padding=k // 2)
+    outs = [torch.full((b, h * w, cout), float("nan"), dtype=F16, device=dev) for _ in range(3)]
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+
+    def call(o=outs[0]):
+        ops.igemm(x16[0], w16, cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cins[0], ksize=k, a1=x16[1] if len(cins) > 1 else None,
+                  c1=cins[1] if len(cins) > 1 else 0, bias=bias, out=o, ws=ws, force_cfg=cfg, force_splitk=splitk, w_tiled=tiled)
+    if not _igemm_or_refused(cfg, k, w, call):
+        return
+    call(outs[1])
+    call(outs[2])
+    torch.cuda.synchronize()
+    assert _err(_nchw32(outs[0], b, h, w), ref) <= 4e-3 * max(1.0, float(ref.abs().max())), (name, cfg)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (name, cfg, "not deterministic")
+
+
+@pytest.mark.parametrize("cfg", RING_CFGS)
+def test_ring_rejects_what_it_cannot_do(dev, cfg):
+    """stride 2, upsample and ragged channel counts belong to the 2-stage kernels"""
+    from magicdance_amd import ops, _lib
+    x = torch.zeros((1, 256, 64), dtype=F16, device=dev)
+    w9 = torch.zeros((64, 576), dtype=F16, device=dev)
+    with pytest.raises(_lib.MagicDanceHipError):
+        ops.igemm(x, w9, 64, batch=1, hin=16, win=16, hout=8, wout=8, c0=64, ksize=3, stride=2, out=torch.empty((1, 64, 64), dtype=F16, device=dev),
+                  force_cfg=cfg)
+    with pytest.raises(_lib.MagicDanceHipError):
+        ops.igemm(x, w9, 64, batch=1, hin=16, win=16, hout=32, wout=32, c0=64, ksize=3, ups=1, out=torch.empty((1, 1024, 64), dtype=F16, device=dev),
+                  force_cfg=cfg)
+    x2 = torch.zeros((1, 256, 96), dtype=F16, device=dev)
+    with pytest.raises(_lib.MagicDanceHipError):
+        ops.igemm(x2, torch.zeros((64, 96), dtype=F16, device=dev), 64, batch=1, hin=16, win=16, hout=16, wout=16, c0=96,
+                  out=torch.empty((1, 256, 64), dtype=F16, device=dev), force_cfg=cfg)
+
+
+@pytest.mark.parametrize("cfg", RING_CFGS)
+def test_ring_epilogues(dev, cfg):
+    """every epilogue family behind the ring loop: GEGLU, fused q|k + V^T with the column scale, folded LayerNorm (row statistics
+    from the ring's A fragments), the two-term residual stream with and without split-K (3x3), per-sample bias + SiLU."""
+    from magicdance_amd import ops, engine
+    info = ops.igemm_config_info(cfg)
+    b, n, c = 2, 200, 128   # M = 400: not a multiple of any tile
+    x = _rand((b, n, c), 1, dev).to(F16)
+    xr = x.float()
+    nf = info["bn"] // info["wn"] // 16   # fragments per wave along N: GEGLU pairs them
+    if nf % 2 == 0:
+        w1, b1 = _rand((8 * c, c), 3, dev, c ** -0.5), _rand((8 * c,), 4, dev, 0.1)
+        wp, bp = engine.pack_geglu(w1, b1, dev)
+        og = torch.empty((b, n, 4 * c), dtype=F16, device=dev)
+        ops.igemm(x, wp, 8 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, bias=bp, act=ops.MD_ACT_GEGLU, out=og, ld_out=4 * c, force_cfg=cfg)
+        hr = xr @ w1.half().float().t() + b1
+        a, g = hr.chunk(2, dim=-1)
+        assert _err(og, a * F.gelu(g)) <= 6e-3
+    wq = _rand((3 * c, c), 2, dev, c ** -0.5)
+    qk = torch.empty((b, n, 2 * c), dtype=F16, device=dev)
+    vt = torch.zeros((b, c, 208), dtype=F16, device=dev)
+    ops.igemm(x, wq.to(F16).contiguous(), 3 * c, batch=b, hin=1, win=n, hout=1, wout=n, c0=c, out=qk, ld_out=2 * c, out_t=vt,
+              n_tr_begin=2 * c, ld_t=208, col_scale=(0.25, c), force_cfg=cfg)
+    ref = xr @ wq.half().float().t()
+    assert _err(qk[..., :c], ref[..., :c] * 0.25) <= 4e-3 and _err(qk[..., c:], ref[..., c:2 * c]) <= 4e-3
+    assert _err(vt[:, :, :n], ref[..., 2 * c:].transpose(1, 2)) <= 4e-3
+    # folded LayerNorm: rows with mean 1 / std 3, K = 1280 (the ring wraps)
+    cl = 1280
+    xl = (_rand((b, n, cl), 8, dev) * 3 + 1).to(F16)
+    wln = _rand((c, cl), 12, dev, cl ** -0.5)
+    gamma, beta = 1 + 0.1 * _rand((cl,), 9, dev), 0.1 * _rand((cl,), 10, dev)
+    wl, s1, s0 = engine.fold_layernorm(wln, None, gamma, beta, dev)
+    ol = torch.empty((b, n, c), dtype=F16, device=dev)
+    ops.igemm(xl, wl, c, batch=b, hin=1, win=n, hout=1, wout=n, c0=cl, out=ol, ln=(s1, s0, 1e-5), force_cfg=cfg)
+    refl = F.layer_norm(xl.float(), (cl,), gamma, beta) @ wln.t()
+    assert _err(ol, refl) <= 6e-3 * max(1.0, float(refl.abs().max()))
+    # 3x3 conv, two-term residual, with / without split-K; per-sample bias rows + SiLU
+    xc = _rand((2, 128, 8, 8), 5, dev)
+    wt = _rand((128, 128, 3, 3), 6, dev, (128 * 9) ** -0.5)
+    res32 = _rand((2, 128, 8, 8), 7, dev, 3.0)
+    res_hi = _nhwc16(res32)
+    res_lo = (res32.permute(0, 2, 3, 1).reshape(2, 64, 128) - res_hi.float()).to(F16).contiguous()
+    bias_b = _rand((2, 256), 13, dev, 0.5)
+    refc = F.silu(F.conv2d(xc.half().float(), wt.half().float(), None, padding=1) + bias_b[:, 64:192, None, None])
+    refc = refc + _nchw32(res_hi.float() + res_lo.float(), 2, 8, 8)
+    out = torch.empty((2, 64, 128), dtype=F16, device=dev)
+    out_lo = torch.empty((2, 64, 128), dtype=F16, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    for sk in (1, 2):
+        ops.igemm(_nhwc16(xc), engine.pack_conv(wt, dev), 128, batch=2, hin=8, win=8, hout=8, wout=8, c0=128, ksize=3, bias=bias_b[:, 64:],
+                  bias_batch_stride=256, act=ops.MD_ACT_SILU, res=res_hi, ld_res=128, res_lo=res_lo, out=out, out_lo=out_lo, ws=ws,
+                  force_cfg=cfg, force_splitk=sk)
+        assert _err(_nchw32(out.float() + out_lo.float(), 2, 8, 8), refc) <= 3e-5 * float(refc.abs().max()), sk
+
+
+PART_CASES = [
+    ("p_64x320", 2, 320, 16, 16, 320, 3, 0),
+    ("p_1x1", 3, 128, 8, 16, 192, 1, 0),
+    ("p_dual", 3, 64, 8, 8, 128, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", PART_CASES, ids=[c[0] for c in PART_CASES])
+@pytest.mark.parametrize("cfg", RING_CFGS)
+def test_ring_groupnorm_partials(dev, case, cfg):
+    from magicdance_amd import ops, engine
+    name, b, cin, h, w, cout, k, b2 = case
+    x = _rand((b, cin, h, w), 1, dev)
+    wt = _rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5)
+    wt2 = _rand((cout, cin, k, k), 12, dev, (cin * k * k) ** -0.5)
+    bias, bias2 = _rand((cout,), 3, dev, 0.5), _rand((cout,), 13, dev, 0.5)
+    res = _nhwc16(_rand((b, cout, h, w), 4, dev))
+    hw = h * w
+    out = torch.empty((b, hw, cout), dtype=F16, device=dev)
+    part = torch.full((b * hw // 64, 2, cout), float("nan"), dtype=F32, device=dev)
+    set2 = (b2, engine.pack_conv(wt2, dev), bias2, None) if b2 else None
+    ops.igemm(_nhwc16(x), engine.pack_conv(wt, dev), cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, bias=bias,
+              res=res, ld_res=cout, out=out, gn_part=part, force_cfg=cfg, set2=set2)
+    v = out.float().reshape(b * hw // 64, 64, cout)
+    assert bool(torch.isfinite(part).all())
+    assert _err(part[:, 0], v.sum(1)) <= 2e-4 * float(v.abs().sum(1).max())
+    assert _err(part[:, 1], (v * v).sum(1)) <= 2e-4 * float((v * v).sum(1).max())
+    ws_ = [x.half().float()[:b2 or b], x.half().float()[b2:]] if b2 else [x.half().float()]
+    refs = [F.conv2d(ws_[0], wt.half().float(), bias, padding=k // 2)]
+    if b2:
+        refs.append(F.conv2d(ws_[1], wt2.half().float(), bias2, padding=k // 2))
+    ref = torch.cat(refs, 0) + _nchw32(res, b, h, w)
+    assert _err(_nchw32(out, b, h, w), ref) <= 4e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", [("c3", 3, 2, 320, 8, 8, 128, 3), ("c3_ragged", 3, 2, 64, 6, 6, 96, 3), ("c1", 6, 4, 320, 16, 16, 320, 1),
+                                  ("c3_16", 3, 2, 1280, 16, 16, 160, 3)])
+@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_ring_second_parameter_set(dev, case, cfg, splitk):
+    """w2 / bias2 / batch2 through the ring: one launch == two launches on the two sample ranges, bit for bit (the second set's
+    tiles start at its first row, where its haloed A block starts, too)."""
+    from magicdance_amd import ops, engine
+    name, b, b2, cin, h, w, cout, k = case
+    x = _nhwc16(_rand((b, cin, h, w), 1, dev))
+    wa = engine.pack_conv(_rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5), dev)
+    wb = engine.pack_conv(_rand((cout, cin, k, k), 3, dev, (cin * k * k) ** -0.5), dev)
+    ba, bb = _rand((cout,), 4, dev, 0.5), _rand((cout,), 5, dev, 0.5)
+    res = _rand((b, h * w, cout), 6, dev).to(F16)
+    res_lo = (_rand((b, h * w, cout), 7, dev) * 1e-4).to(F16)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    kw = dict(hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, ld_res=cout, act=ops.MD_ACT_SILU, ws=ws, force_cfg=cfg, force_splitk=splitk)
+    one, one_lo = torch.zeros((b, h * w, cout), dtype=F16, device=dev), torch.zeros((b, h * w, cout), dtype=F16, device=dev)
+
+    def merged():
+        ops.igemm(x, wa, cout, batch=b, bias=ba, res=res, res_lo=res_lo, out=one, out_lo=one_lo, set2=(b2, wb, bb, None), **kw)
+    if not _igemm_or_refused(cfg, k, w, merged):
+        return
+    two, two_lo = torch.zeros_like(one), torch.zeros_like(one)
+    ops.igemm(x, wa, cout, batch=b2, bias=ba, res=res, res_lo=res_lo, out=two, out_lo=two_lo, **kw)
+    ops.igemm(x[b2:], wb, cout, batch=b - b2, bias=bb, res=res[b2:], res_lo=res_lo[b2:], out=two[b2:], out_lo=two_lo[b2:], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two) and torch.equal(one_lo, two_lo), (name, cfg, splitk)
+    assert float((one[:b2].float() - one[b2:b2 + 1].float()).abs().max()) > 0.05
+
+
+@pytest.mark.parametrize("cfg", RING_CFGS)
+def test_ring_matches_two_stage_kernels_under_load(dev, cfg):
+    """the step's real small-M shapes with cold weights in rotation and a bandwidth hog on a second stream: repeated launches stay
+    bit-identical to the first (a counted wait that is one load short shows up here, not on an idle chip)"""
+    from magicdance_amd import ops
+    hog_src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    for (b, hh, cin, n, k) in ((3, 8, 1280, 1280, 3), (2, 16, 1280, 1280, 1), (2, 16, 640, 1280, 3)):
+        if not _fits(cfg, k, hh):
+            continue
+        x = _rand((b, hh * hh, cin), 1, dev).to(F16)
+        wts = [ops.tile_weights((_rand((n, k * k * cin), 2 + i, dev) * (k * k * cin) ** -0.5).to(F16), k) for i in range(3)]
+        refs = []
+        for wt in wts:
+            o = torch.empty((b, hh * hh, n), dtype=F16, device=dev)
+            ops.igemm(x, wt, n, batch=b, hin=hh, win=hh, hout=hh, wout=hh, c0=cin, ksize=k, out=o, ws=ws, force_cfg=cfg, w_tiled=True)
+            refs.append(o)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                hog_dst.copy_(hog_src)
+        for rep in range(4):
+            for wt, r in zip(wts, refs):
+                o = torch.empty_like(r)
+                ops.igemm(x, wt, n, batch=b, hin=hh, win=hh, hout=hh, wout=hh, c0=cin, ksize=k, out=o, ws=ws, force_cfg=cfg, w_tiled=True)
+                assert torch.equal(o, r), (cfg, b, hh, cin, n, k, rep)
+        torch.cuda.synchronize()
+        # and against the 2-stage kernels (different summation order: accumulation noise only)
+        o2 = torch.empty_like(refs[0])
+        ops.igemm(x, wts[0], n, batch=b, hin=hh, win=hh, hout=hh, wout=hh, c0=cin, ksize=k, out=o2, ws=ws, force_cfg=15, w_tiled=True)
+        assert _err(o2, refs[0]) <= 4e-3 * max(1.0, float(o2.float().abs().max()))

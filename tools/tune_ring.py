@@ -1,0 +1,163 @@
+"""Tune md_igemm's RING form (configs 40.., igemm_ring.hip) against the committed table's 2-stage choice, shape by shape, on an
+MI355X (GPU box only).  Works from magicdance_amd/csrc/igemm_tuned.inc alone (every entry's comment carries the launch geometry),
+so no model is built.
+
+  python tools/tune_ring.py OUT.inc [--mmin 0] [--mmax 4096] [--margin 0.03] [--reps 12] [--only-ring-layers]
+
+For every stride-1, non-upsampling, 64-channel-aligned entry with mmin <= M <= mmax it times, with cold weights in rotation and
+dependent launches replayed from a captured graph (as tools/tune_igemm.py does):
+  * the committed (config, split, k-groups),
+  * every ring config that fits the LDS, with the split-K factors that give 100 .. 1100 workgroups,
+and writes the whole table to OUT.inc with the entries the ring wins by more than ``margin`` replaced.  Batches of 3 f samples are the
+merged UNet + ControlNet pass (two weight sets: the last third of the samples reads w2), timed that way."""
+import argparse
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from magicdance_amd import ops, _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("out")
+ap.add_argument("--mmin", type=int, default=0)
+ap.add_argument("--mmax", type=int, default=4096)
+ap.add_argument("--margin", type=float, default=0.03)
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--shapes", default="", help="comma separated M:N:K filters (debug)")
+ap.add_argument("--cfgs", default="", help="comma separated ring configs to try (default: all)")
+args = ap.parse_args()
+
+TABLE = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm_tuned.inc")
+ENTRY = re.compile(r"\s*\{(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)(?:,\s*(\d+))?\},\s*//\s*x(\d+).*?\(B=(\d+) (\d+)x(\d+) c=(\d+)\+(\d+)\)(.*)")
+lines = open(TABLE).read().split("\n")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+F16 = torch.float16
+side = torch.cuda.Stream()
+ws = torch.zeros(512 << 20, dtype=torch.uint8, device=dev)
+RING = [c for c in range(40, 40 + 64) if ops.igemm_config_info(c) is not None]
+if args.cfgs:
+    RING = [int(c) for c in args.cfgs.split(",")]
+want = [tuple(int(v) for v in s.split(":")) for s in args.shapes.split(",") if s]
+
+
+def time_launch(run, reps):
+    with torch.cuda.stream(side):
+        run(0)
+        side.synchronize()
+        g = ops.Graph()
+        g.begin()
+        try:
+            for i in range(reps):
+                run(i)
+            g.end()
+        except Exception:
+            g.abort()
+            raise
+        g.launch()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        g.launch()
+        e1.record(side)
+        side.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        g.destroy()
+    return us
+
+
+tot_base, tot_best, nring = 0.0, 0.0, 0
+out_lines = []
+for ln in lines:
+    m = ENTRY.match(ln)
+    if not m:
+        out_lines.append(ln)
+        continue
+    M, N, K, ks, st, up, cfg0, sp0 = (int(v) for v in m.groups()[:8])
+    kg0 = int(m.group(9) or 1)
+    count, B, h, w, c0, c1 = (int(v) for v in m.groups()[9:15])
+    ok = st == 1 and up == 0 and (c0 + c1) % 64 == 0 and c0 % 64 == 0 and args.mmin <= M <= args.mmax and N % 16 == 0
+    if want and (M, N, K) not in want:
+        ok = False
+    if not ok:
+        out_lines.append(ln)
+        continue
+    act = 2 if (ks == 1 and N == 8 * K) else 0
+    dual = B % 3 == 0 and B >= 3
+    b2 = B * 2 // 3 if dual else 0
+    x0 = torch.randn(B, h * w, c0, device=dev).to(F16)
+    x1 = torch.randn(B, h * w, c1, device=dev).to(F16) if c1 else None
+    nw = 2 if dual else 1
+    ncopy = max(2, min(args.reps, int((320 << 20) // max(1, N * K * 2 * nw)) + 1))
+    wts = [[ops.tile_weights((torch.randn(N, K, device=dev) * 0.02).to(F16), ks) for _ in range(nw)] for _ in range(ncopy)]
+    bias, bias2 = torch.randn(N, device=dev), torch.randn(N, device=dev)
+    nout = N // 2 if act == 2 else N
+    out = torch.empty(B, h * w, nout, dtype=F16, device=dev)
+    with_res = ks == 1 and c1 == 0 and act == 0 and N <= K   # the projections that close a residual branch: two-term stream
+    res_t = torch.randn(B, h * w, N, device=dev).to(F16) if with_res else None
+    res_lo_t = (torch.randn(B, h * w, N, device=dev) * 1e-3).to(F16) if with_res else None
+    out_lo_t = torch.empty_like(out) if with_res else None
+
+    def launcher(cfg, sp, kg):
+        def run(i):
+            wa = wts[i % ncopy]
+            ops.igemm(x0, wa[0], N, batch=B, hin=h, win=w, hout=h, wout=w, c0=c0, ksize=ks, a1=x1, c1=c1, bias=bias, act=act, out=out,
+                      ld_out=nout, ws=ws, force_cfg=cfg, force_splitk=sp, force_kg=kg, res=res_t, ld_res=N if with_res else 0,
+                      res_lo=res_lo_t, out_lo=out_lo_t, w_tiled=True, set2=(b2, wa[1], bias2, None) if dual else None)
+        return run
+    res = []
+    try:
+        res.append((time_launch(launcher(cfg0, sp0, kg0), args.reps), cfg0, sp0, kg0))
+    except Exception as ex:  # noqa: BLE001
+        print("ERR base", (M, N, K), cfg0, sp0, kg0, ex, flush=True)
+        out_lines.append(ln)
+        continue
+    base = res[0][0]
+    nk = K // 64
+    units = nk // 9 if ks == 3 else nk   # what the ring splits K in: channel blocks / k-tiles
+    for cfg in RING:
+        c = ops.igemm_config_info(cfg)
+        if ops.ring_lds_bytes(cfg, ks, w) > 160 * 1024:
+            continue
+        if act == 2 and (c["bn"] // c["wn"] // 16) % 2:
+            continue
+        mt = (-(-(b2 * h * w) // c["bm"]) + -(-((B - b2) * h * w) // c["bm"])) if dual else -(-M // c["bm"])
+        tiles = mt * -(-N // c["bn"])
+        if tiles > 2400:
+            continue
+        splits = [1] if tiles >= 96 else []
+        if act != 2:
+            for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+                if s <= units // 2 and 100 <= tiles * s <= 1100 and s * M * N * 4 <= ws.numel():
+                    splits.append(s)
+        if not splits:
+            splits = [max(1, min(units // 2, 128 // max(1, tiles)))] if act != 2 else [1]
+        for sp in sorted(set(splits)):
+            try:
+                res.append((time_launch(launcher(cfg, sp, 0), args.reps), cfg, sp, c["kg"]))
+            except Exception as ex:  # noqa: BLE001
+                print("ERR ring", (M, N, K), cfg, sp, ex, flush=True)
+    res.sort()
+    us, cfg, sp, kg = res[0]
+    if cfg >= 40 and us > (1.0 - args.margin) * base:
+        us, cfg, sp, kg = base, cfg0, sp0, kg0
+    tot_base += base * count
+    tot_best += us * count
+    tag = ""
+    if cfg >= 40:
+        nring += 1
+        tag = f"  [round 4, ring: {base:.1f} -> {us:.1f}us]"
+        out_lines.append(f"    {{{M}, {N}, {K}, {ks}, {st}, {up}, {cfg}, {sp}, {kg}}},  // x{count} {us:.1f}us {2.0 * M * N * K / us / 1e6:.0f}TF "
+                         f"(B={B} {h}x{w} c={c0}+{c1}){tag}")
+    else:
+        out_lines.append(ln)
+    wbytes = N * K * 2 * nw
+    print(f"M={M} N={N} K={K} ks={ks} B={B}{' dual' if dual else ''}{' geglu' if act else ''}{' res' if with_res else ''} x{count}: base c{cfg0}/s{sp0}/g{kg0} {base:.1f}us"
+          f" | best c{cfg}/s{sp} {us:.1f}us ({wbytes / us / 1e6:.2f} TB/s of W, {2.0 * M * N * K / us / 1e6:.0f} TF) | ring:",
+          " ".join(f"c{c_}/s{s_}:{u_:.1f}" for u_, c_, s_, _ in [r for r in res if r[1] >= 40][:6]), flush=True)
+with open(args.out, "w") as f:
+    f.write("\n".join(out_lines))
+print(f"sum over the table's launch counts: committed {tot_base / 1e3:.3f} ms -> best {tot_best / 1e3:.3f} ms; {nring} entries moved to the ring", flush=True)

@@ -115,6 +115,105 @@ def cpu_baseline(model, inp, size, z_hip=None, img_hip=None, steps=3):
             "parity_full_size": parity}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def gpu_state():
+    """sclk / mclk / temperature / power of the GPUs as rocm-smi reports them right now (box variance: a box that clocks low is
+    otherwise indistinguishable from a regression).  Best effort: {} when rocm-smi is missing or prints something else."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "--showclocks", "--showtemp", "--showpower", "--showperflevel", "--json"], capture_output=True,
+                           text=True, timeout=20)
+        raw = json.loads(r.stdout[r.stdout.index("{"):])
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"rocm-smi unavailable: {type(ex).__name__}"}
+    keep = ("sclk", "mclk", "fclk", "socclk", "Temperature (Sensor junction)", "Temperature (Sensor memory)", "Power", "Performance Level")
+    out = {}
+    for card, d in raw.items():
+        if isinstance(d, dict):
+            out[card] = {k: v for k, v in d.items() if any(t.lower() in k.lower() for t in keep)}
+    return out
+
+
+def _latest_profile(pattern):
+    """newest committed profiles/round<N>_<pattern> (highest round number), or None"""
+    import glob
+    import re
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", "round*_" + pattern)):
+        m = re.match(r"round(\d+)_", os.path.basename(p))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), p)
+    return None if best is None else best[1]
+
+
+def roofline_blocks(fam, no_decode, pmc_ok):
+    """`roofline` (igemm, the dominant family), `roofline_attention` and the per-family table from profile_one_step's result"""
+    ig = fam["igemm"]
+    ig_ms = ig.get("graph_ms", ig["ms"])
+    ach = ig["flops"] / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+    # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of configs[1] -- the
+    # 50-step one-frame batch --, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
+    traffic, traffic_src, traffic_kind = None, None, "measured"
+    path = _latest_profile("pmc_summary.json") if pmc_ok else None
+    if path:
+        try:
+            pmc = json.load(open(path))
+            traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), os.path.basename(path)
+            # a summary collected on another launch mix is re-expressed per launch of this run's mix and labelled as derived
+            if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"] and \
+                    abs(pmc["igemm_launches_per_batch"] - ig["launches"]) > 0.01 * ig["launches"]:
+                traffic = traffic * pmc["igemm_launches_per_batch"] / ig["launches"]
+                traffic_kind = f"derived: bytes per batch of a {pmc['igemm_launches_per_batch']}-launch mix over this run's launches"
+        except Exception:  # noqa: BLE001
+            traffic, traffic_src = None, None
+
+    def part(d):
+        if d is None:
+            return None
+        ms = d.get("graph_ms", d["ms"])
+        return {"ms": ms, "launches": d["launches"], "tflops": d["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+    roof = {"bound": "mfma", "kernel": "igemm kernels (all launches of one batch: reference-KV table pass + "
+            f"{ig['ddim_steps']} DDIM steps" + ("" if no_decode else " + first-stage decode") + ")", "achieved": ach,
+            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
+            "traffic_unit": (f"bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_src}, {traffic_kind})" if traffic_src else
+                             "null: the committed PMC passes cover configs[1] only"),
+            "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
+            "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
+            "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,
+            "ms_eager_events": ig["ms"], "table_pass": part(ig["table"]), "ddim_step": part(ig["step"]),
+            "first_stage_decode": part(ig["decode"])}
+    at = fam["attention"]
+    at_ms = at.get("graph_ms", at["ms"])
+    at_ach = at["flops"] / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
+    busy, busy_src = None, None
+    path = _latest_profile("attention_pmc.json")
+    if path:
+        try:
+            pj = json.load(open(path))
+            busy, busy_src = pj.get("mfma_busy"), os.path.basename(path) + ": " + pj.get("what", "")
+        except Exception:  # noqa: BLE001
+            pass
+    roof_at = {"bound": "mfma", "kernel": "attention kernels (all launches of one batch)", "achieved": at_ach, "peak": PEAK_FP16_TFLOPS,
+               "unit": "TFLOP/s", "frac": at_ach / PEAK_FP16_TFLOPS, "ms": at_ms, "launches": at["launches"],
+               "mfma_busy": busy, "mfma_busy_source": busy_src or "null: no committed attention counter summary"}
+    fams = {k: {"ms": v["ms"], "graph_ms": v.get("graph_ms"), "launches": v["launches"],
+                "step_ms": v["step"].get("graph_ms", v["step"]["ms"]),
+                "table_ms": None if v["table"] is None else v["table"].get("graph_ms", v["table"]["ms"]),
+                "decode_ms": None if v["decode"] is None else v["decode"].get("graph_ms", v["decode"]["ms"]),
+                "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
+            for k, v in fam.items()}
+    return roof, roof_at, fams
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,23 +236,60 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every DDIM step un-captured (same launches, no HIP graph): the form the rocprofv3 --pmc passes of "
                          "tools/run_profiles.sh run on (the counter tool does not survive graph replays of the linear step graph)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="run ONLY the rank launch / join protocol (self-spawn of --gpus ranks, process group, join count) and print "
+                         "its JSON line: no model, no kernels (gloo when there is no GPU -- the CPU test tier drives this)")
     args = ap.parse_args()
 
+    # ---- one process per GPU.  The driver's contract is `python bench.py --gpus N`: without a torchrun environment this process
+    # re-executes itself under torch.distributed.run with N ranks (what scripts/inference_any_image_pose.sh:4 does for the reference);
+    # inside one, WORLD_SIZE must BE N -- a run that silently measures fewer ranks than it reports is refused.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node == --gpus "
+                 "(or without a torchrun environment: bench.py spawns the ranks itself)")
+    have_gpu = torch.cuda.is_available()
+    if not args.selftest_launch:
+        if not have_gpu or torch.cuda.device_count() < (local + 1 if world > 1 else 1):
+            sys.exit(f"bench.py: rank {rank} needs cuda:{local}; {torch.cuda.device_count() if have_gpu else 0} GPU(s) visible")
+    if have_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
     dist = None
+    joined = 1
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if have_gpu:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        joined = int(one.item())
+        if joined != args.gpus or dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: {joined} rank(s) joined the process group, --gpus {args.gpus} asked for")
+    if args.selftest_launch:
+        if rank == 0:
+            print(json.dumps({"selftest": "launch", "n_gpus": world, "rccl_ranks": joined,
+                              "backend": (dist.get_backend() if dist is not None else None), "value": None}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from magicdance_amd import synthetic, ops
     from magicdance_amd import parallel, engine
     if args.fp8_attention:
         engine.ATTN_FP8 = True   # read when the engines pack their weights / allocate their K / V^T buffers
+    state0 = gpu_state() if rank == 0 else None
     model = build_model(dev, args.size)
     fpg = args.frames_per_gpu if args.frames_per_gpu else (1 if world == 1 else 8)
     cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get((fpg, world), "configs[3]" if (fpg == 8 and world > 1) else "custom")
@@ -197,7 +333,7 @@ def main():
     assert bool(torch.isfinite(z).all()), "non-finite latents"
     frames = args.steps * (args.sequence if args.sequence else fpg) * world
     out = {"metric": "512x512 frames/sec @ 50 DDIM steps", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "rccl_ranks": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f16 (attention operands e4m3)" if args.fp8_attention else "f16", "data": "synthetic",
            "ms_per_ddim_step": 1e3 * dt / args.steps / args.ddim_steps,
            "config": {"workload": (f"sequence of {args.sequence} frames/GPU sharing one reference (bank table once per sequence), "
@@ -207,6 +343,8 @@ def main():
                                   ("latents out" if args.no_decode else "first-stage-decoded frames out"),
                       "frames_per_gpu": fpg, "ddim_steps": args.ddim_steps, "weights": "seeded synthetic, SD-1.5 geometry",
                       "parallelism": f"frame-shard x{world}"}}
+    if rank == 0:
+        out["gpu_state"] = {"before_load": state0, "after_timed_region": gpu_state(), "source": "rocm-smi --showclocks --showtemp --showpower"}
     if world > 1:
         # the N = 1 line's `value` is configs[1] (ONE frame per batch, the headline metric); the per-GPU work of this line is the
         # N = 1 line's `extra` entry -- that is the one-GPU figure a scaling efficiency of this line is to be taken against
@@ -217,53 +355,8 @@ def main():
         # HIP events on un-captured launches (ms_eager_events, includes eager launch latency) and, for igemm / attention,
         # the same launches replayed from a captured graph between two HIP events on the launch stream (graph_ms)
         fam = runner.profile_one_step(pose, ctx, ref, x_T, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
-        ig = fam["igemm"]
-        ig_ms = ig.get("graph_ms", ig["ms"])
-        ach = ig["flops"] / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS
-        # workload -- the 50-step batch --, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
-        traffic, traffic_src = None, None
-        traffic_kind = "measured"
-        for cand in ("round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                traffic, traffic_src = pmc.get("igemm_hbm_bytes_per_launch"), cand
-                # round 3: the counters are collected on THIS launch mix (bench.py --no-graph: the default merged pass, un-captured).
-                # An older summary (other launch mix) is re-expressed per launch of this run's mix and labelled as derived.
-                # (the counter run also sees the one-time launches of the first batch -- context K / V projections, hint encoder --:
-                #  a launch count within 1 % of this run's is the same mix)
-                if traffic and pmc.get("igemm_launches_per_batch") and ig["launches"] and \
-                        abs(pmc["igemm_launches_per_batch"] - ig["launches"]) > 0.01 * ig["launches"]:
-                    traffic = traffic * pmc["igemm_launches_per_batch"] / ig["launches"]
-                    traffic_kind = f"derived: bytes per batch of a {pmc['igemm_launches_per_batch']}-launch mix over this run's launches"
-                if not (args.ddim_steps == 50 and fpg == 1 and args.size == 64 and not args.sequence):
-                    traffic, traffic_src = None, None   # the counters were collected on configs[1] only
-                break
-            except Exception:  # noqa: BLE001
-                pass
-
-        def part(d):
-            if d is None:
-                return None
-            ms = d.get("graph_ms", d["ms"])
-            return {"ms": ms, "launches": d["launches"], "tflops": d["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (all launches of one batch: reference-KV table pass + "
-                           f"{ig['ddim_steps']} DDIM steps" + ("" if args.no_decode else " + first-stage decode") + ")", "achieved": ach,
-                           "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
-                           "traffic_unit": (f"bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_src}, {traffic_kind})" if traffic_src else
-                                            "null: the PMC passes (profiles/round3_pmc_summary.json) cover configs[1] only"),
-                           "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
-                           "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
-                           "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,
-                           "ms_eager_events": ig["ms"], "table_pass": part(ig["table"]), "ddim_step": part(ig["step"]),
-                           "first_stage_decode": part(ig["decode"])}
-        out["families_ms_per_batch"] = {k: {"ms": v["ms"], "graph_ms": v.get("graph_ms"), "launches": v["launches"],
-                                            "step_ms": v["step"].get("graph_ms", v["step"]["ms"]),
-                                            "table_ms": None if v["table"] is None else v["table"].get("graph_ms", v["table"]["ms"]),
-                                            "decode_ms": None if v["decode"] is None else v["decode"].get("graph_ms", v["decode"]["ms"]),
-                                            "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
-                                            "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
-                                        for k, v in fam.items()}
+        pmc_ok = args.ddim_steps == 50 and fpg == 1 and args.size == 64 and not args.sequence   # the counters were collected on configs[1]
+        out["roofline"], out["roofline_attention"], out["families_ms_per_batch"] = roofline_blocks(fam, args.no_decode, pmc_ok)
     if rank == 0 and not args.no_roofline:
         # metric (ii), "UNet ms/step": one forward of each network at B = 1 and B = 8, graph-replayed between HIP events
         nets = {}
@@ -272,19 +365,25 @@ def main():
             nets[f"B{bb}"] = runner.network_pass_times(pi["pose"], ctx, ref, pi["x_T"].repeat(bb, 1, 1, 1), ddim_steps=args.ddim_steps)
         out["unet_ms_per_step"] = nets
     if rank == 0 and world == 1 and fpg == 1 and not args.sequence and not args.no_extra:
-        # extra line: BASELINE configs[2] (8 frames as one batch on one GPU), same timing protocol, 1 warm-up + 2 timed batches
+        # extra line: BASELINE configs[2] (8 frames as one batch on one GPU -- "the roofline run"), same timing protocol, 1 warm-up +
+        # 5 timed batches, with its own roofline blocks
         p8 = synthetic.synth_inputs((args.size, args.size), frames=8, seed=0, device=dev)
         x8 = p8["x_T"].repeat(8, 1, 1, 1)
         runner.sample(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
         torch.cuda.synchronize()
+        n8 = 5
         t0 = time.time()
-        for _ in range(2):
+        for _ in range(n8):
             runner.sample(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
         torch.cuda.synchronize()
-        d8 = (time.time() - t0) / 2
-        out["extra"] = {"configs[2]": {"workload": "8 frames as one batch, 512x512, 50-step DDIM, decoded frames out", "value": 8 / d8,
-                                       "unit": "frames/s", "ms_per_step": 1e3 * d8, "ms_per_ddim_step": 1e3 * d8 / args.ddim_steps,
-                                       "steps": 2, "warmup": 1}}
+        d8 = (time.time() - t0) / n8
+        e8 = {"workload": "8 frames as one batch, 512x512, 50-step DDIM, decoded frames out", "value": 8 / d8,
+              "unit": "frames/s", "ms_per_step": 1e3 * d8, "ms_per_ddim_step": 1e3 * d8 / args.ddim_steps,
+              "steps": n8, "warmup": 1}
+        if not args.no_roofline:
+            fam8 = runner.profile_one_step(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
+            e8["roofline"], e8["roofline_attention"], e8["families_ms_per_batch"] = roofline_blocks(fam8, args.no_decode, False)
+        out["extra"] = {"configs[2]": e8}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         z_one = runner.sample(pose[:1], ctx, ref, x_T[:1], ddim_steps=args.ddim_steps, scale=7.0) if not args.no_decode else None
         out["cpu_baseline"] = cpu_baseline(model, inp, args.size, z_one,

@@ -189,24 +189,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
-  static_assert((KG - 1) * NF * MF * 4096 + (LN ? (KG - 1) * MF * 2 * 1024 : 0) <= LDS_TOTAL, "cross-group reduction fits the stage memory");
+  constexpr int NTG = 64 * WAVES_M * WAVES_N;   // threads per k-group: 256 (four waves), or 512 for the ring form's 8-wave tiles
+  static_assert((KG - 1) * NF * MF * NTG * 16 + (LN ? (KG - 1) * MF * 2 * NTG * 4 : 0) <= LDS_TOTAL, "cross-group reduction fits the stage memory");
   const int lane = tid & 63;
   const int lr = lane & 15, lg = lane >> 4;
   // ---- k-groups: fixed-order sum of the groups' accumulators (and LayerNorm row sums) through LDS ------------------------------
   if constexpr (KG > 1) {
     __syncthreads();   // every group is done reading its stages
     f4* const red = reinterpret_cast<f4*>(smem);
-    float* const red_ln = reinterpret_cast<float*>(smem + (KG - 1) * NF * MF * 4096);
+    float* const red_ln = reinterpret_cast<float*>(smem + (KG - 1) * NF * MF * NTG * 16);
     if (kg > 0) {
 #pragma unroll
       for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < MF; ++j) red[((kg - 1) * NF * MF + i * MF + j) * 256 + tid] = acc[i][j];
+        for (int j = 0; j < MF; ++j) red[((kg - 1) * NF * MF + i * MF + j) * NTG + tid] = acc[i][j];
       if constexpr (LN) {
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
-          red_ln[((kg - 1) * MF * 2 + 2 * j) * 256 + tid] = ln_sum[j];
-          red_ln[((kg - 1) * MF * 2 + 2 * j + 1) * 256 + tid] = ln_sq[j];
+          red_ln[((kg - 1) * MF * 2 + 2 * j) * NTG + tid] = ln_sum[j];
+          red_ln[((kg - 1) * MF * 2 + 2 * j + 1) * NTG + tid] = ln_sq[j];
         }
       }
     }
@@ -217,12 +218,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
 #pragma unroll
         for (int i = 0; i < NF; ++i)
 #pragma unroll
-          for (int j = 0; j < MF; ++j) acc[i][j] += red[((q - 1) * NF * MF + i * MF + j) * 256 + tid];
+          for (int j = 0; j < MF; ++j) acc[i][j] += red[((q - 1) * NF * MF + i * MF + j) * NTG + tid];
         if constexpr (LN) {
 #pragma unroll
           for (int j = 0; j < MF; ++j) {
-            ln_sum[j] += red_ln[((q - 1) * MF * 2 + 2 * j) * 256 + tid];
-            ln_sq[j] += red_ln[((q - 1) * MF * 2 + 2 * j + 1) * 256 + tid];
+            ln_sum[j] += red_ln[((q - 1) * MF * 2 + 2 * j) * NTG + tid];
+            ln_sq[j] += red_ln[((q - 1) * MF * 2 + 2 * j + 1) * NTG + tid];
           }
         }
       }
@@ -279,7 +280,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
     if constexpr (NF % 2 == 0) {
       constexpr int SROWH = BN / 2 + 8;   // fp16 row stride (16-byte aligned rows)
       constexpr int CHG = BN / 16;        // 16-byte pieces per tile row
-      constexpr int NT = 256 * KG;
+      constexpr int NT = NTG * KG;
       constexpr int U = (BM * CHG + NT - 1) / NT;
       static_assert(BM * SROWH * 2 <= LDS_TOTAL, "staged GEGLU tile fits the stage memory");
       half_t* const stg = reinterpret_cast<half_t*>(smem);
@@ -356,7 +357,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
     constexpr int RR = BM / ROUNDS;               // tile rows per round
     constexpr int WPR = WAVES_M / ROUNDS;         // wave rows per round
     constexpr int CH = BN / 8;                    // 16-byte output pieces per tile row
-    constexpr int NT = 256 * KG;
+    constexpr int NT = NTG * KG;
     constexpr int U = (RR * CH + NT - 1) / NT;
     float* const stg = reinterpret_cast<float*>(smem);
     const float* __restrict__ const bp = gbias;
@@ -577,6 +578,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
 // ---- the ring form (igemm_ring.hip): tile configs 40.. -----------------------------------------------------------------------
 struct RingCfg {
   int bm, bn, wm, wn, kt, kg, d1, d9;   // tile, waves, k-tiles per group and step, k-groups, ring slots for 1x1 / 3x3 layers
+  int pipe = 0;                         // 1: register-pipelined loop (single k-tiles)
 };
 constexpr int kFirstRingCfg = 40;
 int ring_num_cfgs();

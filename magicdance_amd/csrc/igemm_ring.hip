@@ -15,7 +15,8 @@
 //     all nine taps; tap (dy, dx) of output pixel m reads block row (m - m0) + dy * win + dx, and padding taps read a zero row
 //     (per-lane 9-bit validity masks, computed once).  L2 -> LDS activation traffic drops by BM * 9 / (BM + 2 win + 2): 4.4x at the
 //     64 x 64 level, 7.9x at 8 x 8 -- what remains of the k-loop's vector-memory traffic is the weight stream itself.
-//   * all 4 KG waves of a workgroup load every tile cooperatively (wave w issues the 8-row pieces w, w + 4 KG, ...).
+//   * all waves of a workgroup (4 or 8 per k-group x KG k-groups) load every tile cooperatively (wave w issues the 8-row pieces
+//     w, w + waves, ...).
 // Same tile mapping (XCD-aware grouped raster, second parameter set, split-K over blockIdx.z in units of whole channel blocks),
 // same MFMA fragment layout and the same epilogue (igemm_core.h) as the 2-stage kernels.
 //
@@ -27,9 +28,20 @@ namespace {
 
 // s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier -- n is wave-uniform and only known at run time; the count field is an immediate.
 // A smaller count than asked for is merely stricter, so n > 40 waits for 40.
+// ``steady``: the count of a full ring (every step of a long k-loop but its first and last few) -- one compare instead of the
+// search tree of the switch.
+template <int STEADY_A, int STEADY_B>
 __device__ __forceinline__ void ring_wait_barrier(int n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   n = n < 0 ? 0 : n;
+  if (n == STEADY_A) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(STEADY_A) : "memory");
+    return;
+  }
+  if (STEADY_B != STEADY_A && n == STEADY_B) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(STEADY_B) : "memory");
+    return;
+  }
 #define MD_RW(k)                                                                     \
   case k:                                                                            \
     asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
@@ -49,15 +61,17 @@ __device__ __forceinline__ void ring_wait_barrier(int n) {
 // n / 9 for 0 <= n < 74898 (k-tile index -> channel block; uniform, scalar)
 __device__ __forceinline__ int div9(int n) { return (int)(((unsigned)n * 58255u) >> 19); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KT, int D, int KG, int TAPS, bool LN>
-__global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KT, int D, int KG, int TAPS, bool LN, bool PIPE = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void igemm_ring_kernel(const IgemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(TAPS == 1 || TAPS == 9, "1x1 / linear layers and 3x3 convs");
   static_assert(!LN || TAPS == 1, "LayerNorm folding belongs to the linear layers");
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per k-group");
+  static_assert(WAVES_M * WAVES_N == 4 || (WAVES_M * WAVES_N == 8 && KG == 1), "4 waves per k-group, or one 8-wave group");
+  constexpr int WG = WAVES_M * WAVES_N;   // waves per k-group
+  constexpr int NTG = 64 * WG;            // threads per k-group
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
-  constexpr int NW = 4 * KG;            // waves per workgroup: all of them load every tile
+  constexpr int NW = WG * KG;           // waves per workgroup: all of them load every tile
   constexpr int TS = KG * KT;           // k-tiles per step (one ring slot)
   constexpr int TILE_W = BN * 128, TILE_A = BM * 128;
   constexpr int SLOT_W = TS * TILE_W, SLOT_A = TAPS == 1 ? TS * TILE_A : 0;
@@ -66,12 +80,13 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
   constexpr int WJ = (RBW + NW - 1) / NW, AJ = (RBA + NW - 1) / NW;
   static_assert(BM % 32 == 0 && BN % 16 == 0 && WTM <= 64, "tile shape");
   static_assert(D >= 2 && D <= 12 && TS <= 8, "ring depth; a step never reaches beyond the next channel block");
+  static_assert(!PIPE || TS == 1, "the register-pipelined loop walks single k-tiles");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x & 255;   // thread within its k-group
+  const int tid = threadIdx.x & (NTG - 1);   // thread within its k-group
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTG);
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave within the workgroup (loader role)
   const int lr = lane & 15, lg = lane >> 4;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -206,9 +221,13 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
         aseq0 = tot;
     }
   }
-  int wq[D - 1];   // wq[i]: sequence number of the last load of compute step (current + i)
+  // wq[i]: sequence number of the last load of compute step (current + i).  The plain loop refills a slot when the NEXT step's
+  // barrier has passed (D - 1 steps in flight ahead of the prologue), the register-pipelined one when the step's last fragment read
+  // has (all D slots filled up front)
+  constexpr int NQ = PIPE ? D : D - 1;
+  int wq[NQ];
 #pragma unroll
-  for (int i = 0; i < D - 1; ++i) {
+  for (int i = 0; i < NQ; ++i) {
     if (i < nsteps) issue_step(i, i);
     wq[i] = tot;
   }
@@ -245,9 +264,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
     for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
   }
 
-  // one k-tile: all operand fragments requested from LDS, then the MFMAs (two 32-deep k-steps)
-  auto compute_tile = [&](const char* Wt, [[maybe_unused]] const char* At, [[maybe_unused]] int kt) {
-    h8 af[2][MF], wf[2][NF];
+  // operand fragments of k-step ks (32 deep) of one k-tile: this wave's MF A fragments and NF W fragments
+  auto load_frags = [&](const char* Wt, [[maybe_unused]] const char* At, [[maybe_unused]] int kt, int ks, h8 (&af)[MF], h8 (&wf)[NF]) {
     if constexpr (TAPS == 9) {
       const int cb = div9(kt), tap = kt - 9 * cb;
       const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
@@ -258,49 +276,98 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
         const int row = wm * WTM + i * 16 + lr + tapoff;
         int off = ablk + row * 128 + ((lg ^ (row & 7)) << 4);
         off = ((amask[i] >> tap) & 1) ? off : zero_off;
-        af[0][i] = *reinterpret_cast<const h8*>(smem + off);
-        af[1][i] = *reinterpret_cast<const h8*>(smem + (off ^ 64));   // chunk 4 + lg of the same row (the zero row is 128 bytes)
+        af[i] = *reinterpret_cast<const h8*>(smem + (off ^ (ks << 6)));   // ks 1: chunk 4 + lg of the same row (the zero row is 128 B)
       }
     } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          const int row = wm * WTM + i * 16 + lr;
-          af[ks][i] = *reinterpret_cast<const h8*>(At + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
-        }
+      for (int i = 0; i < MF; ++i) {
+        const int row = wm * WTM + i * 16 + lr;
+        af[i] = *reinterpret_cast<const h8*>(At + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < NF; ++i) {
+      const int row = wn * WTN + i * 16 + lr;
+      wf[i] = *reinterpret_cast<const h8*>(Wt + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+    }
+  };
+  auto mma = [&](const h8 (&af)[MF], const h8 (&wf)[NF]) {
+    if constexpr (LN) {
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const int row = wn * WTN + i * 16 + lr;
-        wf[ks][i] = *reinterpret_cast<const h8*>(Wt + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
-      }
+      for (int i = 0; i < MF; ++i) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (LN) {
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
-            ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
-            ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const h2v p = {af[i][2 * e], af[i][2 * e + 1]};
+          ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
+          ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
         }
       }
-#pragma unroll
-      for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int j = 0; j < MF; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+  };
+  // one k-tile: all operand fragments requested from LDS, then the MFMAs (two 32-deep k-steps)
+  auto compute_tile = [&](const char* Wt, [[maybe_unused]] const char* At, [[maybe_unused]] int kt) {
+    h8 af[2][MF], wf[2][NF];
+    load_frags(Wt, At, kt, 0, af[0], wf[0]);
+    load_frags(Wt, At, kt, 1, af[1], wf[1]);
+    mma(af[0], wf[0]);
+    mma(af[1], wf[1]);
   };
 
   // ---- the ring -------------------------------------------------------------------------------------------------------------------
+  constexpr int PER_A = TS * (WJ + (TAPS == 1 ? AJ : 0)), PER_B = TS * ((RBW % NW ? WJ - 1 : WJ) + (TAPS == 1 ? (RBA % NW ? AJ - 1 : AJ) : 0));
+  if constexpr (PIPE) {
+    // Register-pipelined form (single k-tiles): the fragments of a tile's first k-step are read BEFORE the barrier that retires the
+    // previous tile's slot, its second k-step's during the first's MFMAs -- the matrix pipe has work on both sides of every barrier
+    // instead of idling through a lock-step fragment-read phase, and a slot is refilled one step earlier (D - 1 tiles in flight).
+    //   iteration s:  read(s, ks 1) | MFMA(s, ks 0) | wait + barrier: tile s + 1 landed, tile s fully read | refill slot of s with
+    //                 tile s + D | read(s + 1, ks 0) | MFMA(s, ks 1)
+    h8 afA[MF], wfA[NF], afB[MF], wfB[NF];
+    constexpr int ST_A = (D - 2) * PER_A < 40 ? (D - 2) * PER_A : 40, ST_B = (D - 2) * PER_B < 40 ? (D - 2) * PER_B : 40;
+    auto wait_for = [&](int kt, int need) {   // this wave's loads of tile kt (and of its A block) have landed; then the barrier
+      if constexpr (TAPS == 9) need = max(need, (div9(kt) & 1) ? aseq1 : aseq0);
+      ring_wait_barrier<ST_A, ST_B>(tot - need);
+    };
+    if (nsteps > 0) {
+      wait_for(kt_begin, wq[0]);
+      load_frags(smem, smem + D * SLOT_W, kt_begin, 0, afA, wfA);
+    }
+    int cslot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const int kt = kt_begin + s;
+      const char* const ws = smem + cslot * SLOT_W;
+      [[maybe_unused]] const char* const as = smem + D * SLOT_W + cslot * SLOT_A;
+      load_frags(ws, as, kt, 1, afB, wfB);
+      mma(afA, wfA);
+      if (s + 1 < nsteps) {
+        wait_for(kt + 1, wq[1]);   // (lgkmcnt(0) in there: the reads of tile s have left the LDS -> its slot is free)
+#pragma unroll
+        for (int i = 0; i + 1 < D; ++i) wq[i] = wq[i + 1];
+        if constexpr (TAPS == 9) {
+          const int cbmin = div9(kt + 1);
+          if (a_issued <= cbmin && cbmin + 1 < cb_end) {
+            issue_a_block(cbmin + 1);
+            a_issued = cbmin + 1;
+            if (a_issued & 1)
+              aseq1 = tot;
+            else
+              aseq0 = tot;
+          }
+        }
+        if (s + D < nsteps) issue_step(s + D, cslot);
+        wq[D - 1] = tot;
+        const int nslot = cslot + 1 == D ? 0 : cslot + 1;
+        load_frags(smem + nslot * SLOT_W, smem + D * SLOT_W + nslot * SLOT_A, kt + 1, 0, afA, wfA);
+        cslot = nslot;
+      }
+      mma(afB, wfB);
+    }
+  } else {
   int cslot = 0, islot = D - 1;   // slot of the step being computed / of the step issued next (= the slot freed by the barrier)
   for (int s = 0; s < nsteps; ++s) {
     int need = wq[0];
@@ -312,7 +379,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
     }
     // this wave's loads of step s have landed; every wave's reads of step s - 1 are done -> the barrier publishes step s and
     // frees slot (s - 1) % D (and, 3x3, every A block before the one step s starts in)
-    ring_wait_barrier(tot - need);
+    // steady state of a full ring: D - 2 steps issued since; per step a wave issues KG * KT * (WJ or WJ - 1) W pieces (+ A pieces)
+    ring_wait_barrier<(D - 2) * PER_A < 40 ? (D - 2) * PER_A : 40, (D - 2) * PER_B < 40 ? (D - 2) * PER_B : 40>(tot - need);
     if constexpr (TAPS == 9) {
       const int cbmin = div9(kt_begin + s * TS);
       if (a_issued <= cbmin && cbmin + 1 < cb_end) {
@@ -337,9 +405,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_ring_kernel(const IgemmArgs g)
       if (kt < kt_end) compute_tile(ws + t * TILE_W, as + t * TILE_A, kt);
     }
   }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is outstanding here; keeps the epilogue's LDS reuse independent of that)
 
-  igemm_epilogue<BM, BN, WAVES_M, WAVES_N, LN, KG, RING_BYTES>(g, smem, acc, ln_sum, ln_sq, tid, kg, wm, wn, m0, n0, Mlim, kz, gbias, gln_s1,
+  // (3x3: the launch also holds two A blocks of >= BM rows each behind the ring -- the epilogue may stage through them too)
+  igemm_epilogue<BM, BN, WAVES_M, WAVES_N, LN, KG, RING_BYTES + (TAPS == 9 ? 2 * BM * 128 : 0)>(g, smem, acc, ln_sum, ln_sq, tid, kg, wm, wn, m0, n0, Mlim, kz, gbias, gln_s1,
                                                                gln_s0);
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -360,10 +430,26 @@ const RingCfg kRing[] = {
     {128, 128, 2, 2, 1, 1, 4, 5},   // 50
     {256, 64, 4, 1, 1, 1, 3, 10},   // 51
     {64, 160, 2, 2, 1, 1, 5, 5},    // 52
+    // 8-wave tiles (one k-group of 4 x 2 waves, two waves per SIMD sharing every W tile and A block): the large-M layers -- the
+    // reference-KV table pass, multi-frame batches, the first-stage decode -- where the 3x3 convs of the 2-stage kernels are bound
+    // by L2 -> LDS operand traffic (57 B/clk/CU asked of a 128 x 160 tile at the full MFMA rate); a haloed 256-row A block asks 20
+    {256, 160, 4, 2, 1, 1, 2, 3},   // 53
+    {256, 128, 4, 2, 1, 1, 3, 3},   // 54
+    {256, 160, 4, 2, 1, 1, 2, 2},   // 55
+    {128, 160, 4, 2, 1, 1, 4, 4},   // 56
+    {128, 128, 4, 2, 1, 1, 4, 5},   // 57
+    // the same tiles with the register-pipelined loop (fragments of the next k-step / tile read under the MFMAs of this one)
+    {256, 160, 4, 2, 1, 1, 2, 3, 1},   // 58
+    {256, 128, 4, 2, 1, 1, 3, 3, 1},   // 59
+    {256, 160, 4, 2, 1, 1, 2, 2, 1},   // 60
+    {128, 160, 4, 2, 1, 1, 4, 4, 1},   // 61
+    {128, 128, 4, 2, 1, 1, 4, 5, 1},   // 62
+    {128, 160, 2, 2, 1, 1, 4, 4, 1},   // 63
+    {64, 80, 4, 1, 1, 1, 8, 9, 1},     // 64
 };
 constexpr int kNumRing = sizeof(kRing) / sizeof(kRing[0]);
 
-template <int BM, int BN, int WMv, int WNv, int KT, int D, int KG, int TAPS, bool LN>
+template <int BM, int BN, int WMv, int WNv, int KT, int D, int KG, int TAPS, bool LN, bool PIPE>
 int launch_ring_k(const IgemmArgs& g, hipStream_t s) {
   constexpr int ring_bytes = D * KG * KT * (BN + (TAPS == 1 ? BM : 0)) * 128;
   const size_t lds = (size_t)ring_bytes + (TAPS == 9 ? (size_t)2 * g.ring_a_rows * 128 + 128 : 0);
@@ -372,21 +458,21 @@ int launch_ring_k(const IgemmArgs& g, hipStream_t s) {
   int devi = 0;
   MD_HIP_CHECK(hipGetDevice(&devi));
   if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN>),
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN, PIPE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (devi >= 0 && devi < 64) attr_set[devi] = true;
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
-  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN>), grid, dim3(256 * KG), lds, s, g);
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, WMv, WNv, KT, D, KG, TAPS, LN, PIPE>), grid, dim3(64 * WMv * WNv * KG), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
 
-template <int BM, int BN, int WMv, int WNv, int KT, int KG, int D1, int D9>
+template <int BM, int BN, int WMv, int WNv, int KT, int KG, int D1, int D9, bool PIPE = false>
 int launch_ring_t(const IgemmArgs& g, hipStream_t s) {
-  if (g.ksize == 3) return launch_ring_k<BM, BN, WMv, WNv, KT, D9, KG, 9, false>(g, s);
-  if (g.ln_s1) return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, true>(g, s);
-  return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, false>(g, s);
+  if (g.ksize == 3) return launch_ring_k<BM, BN, WMv, WNv, KT, D9, KG, 9, false, PIPE>(g, s);
+  if (g.ln_s1) return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, true, PIPE>(g, s);
+  return launch_ring_k<BM, BN, WMv, WNv, KT, D1, KG, 1, false, PIPE>(g, s);
 }
 
 }  // namespace
@@ -425,6 +511,18 @@ int igemm_ring_launch(const IgemmArgs& g, int cfg, hipStream_t s) {
     case 50: return launch_ring_t<128, 128, 2, 2, 1, 1, 4, 5>(g, s);
     case 51: return launch_ring_t<256, 64, 4, 1, 1, 1, 3, 10>(g, s);
     case 52: return launch_ring_t<64, 160, 2, 2, 1, 1, 5, 5>(g, s);
+    case 53: return launch_ring_t<256, 160, 4, 2, 1, 1, 2, 3>(g, s);
+    case 54: return launch_ring_t<256, 128, 4, 2, 1, 1, 3, 3>(g, s);
+    case 55: return launch_ring_t<256, 160, 4, 2, 1, 1, 2, 2>(g, s);
+    case 56: return launch_ring_t<128, 160, 4, 2, 1, 1, 4, 4>(g, s);
+    case 57: return launch_ring_t<128, 128, 4, 2, 1, 1, 4, 5>(g, s);
+    case 58: return launch_ring_t<256, 160, 4, 2, 1, 1, 2, 3, true>(g, s);
+    case 59: return launch_ring_t<256, 128, 4, 2, 1, 1, 3, 3, true>(g, s);
+    case 60: return launch_ring_t<256, 160, 4, 2, 1, 1, 2, 2, true>(g, s);
+    case 61: return launch_ring_t<128, 160, 4, 2, 1, 1, 4, 4, true>(g, s);
+    case 62: return launch_ring_t<128, 128, 4, 2, 1, 1, 4, 5, true>(g, s);
+    case 63: return launch_ring_t<128, 160, 2, 2, 1, 1, 4, 4, true>(g, s);
+    case 64: return launch_ring_t<64, 80, 4, 1, 1, 1, 8, 9, true>(g, s);
     default: return MD_ERR_BAD_ARG;
   }
 }

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 F16, F32 = torch.float16, torch.float32
-RING_CFGS = list(range(40, 53))
+RING_CFGS = list(range(40, 65))
 
 
 @pytest.fixture(scope="module")

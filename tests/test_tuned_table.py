@@ -8,6 +8,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INC = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm_tuned.inc")
 HIP = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm.hip")
+RING = os.path.join(ROOT, "magicdance_amd", "csrc", "igemm_ring.hip")
 PAT = re.compile(r"\s*\{(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)(?:,\s*(\d+))?\}")
 
 
@@ -34,6 +35,23 @@ def _max_kg():
     return mk
 
 
+def _ring_cfgs():
+    """kRing of igemm_ring.hip: config id -> (bm, bn, wm, wn, kt, kg, d1, d9); ids are kFirstRingCfg + index"""
+    src = open(RING).read()
+    first = int(re.search(r"kFirstRingCfg = (\d+)", open(os.path.join(os.path.dirname(RING), "igemm_core.h")).read()).group(1))
+    body = src[src.index("const RingCfg kRing[] = {"):]
+    body = body[:body.index("};")]
+    rows = re.findall(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},\s*//\s*(\d+)", body)
+    out = {}
+    for i, r in enumerate(rows):
+        assert int(r[9]) == first + i, "kRing comment ids follow the array order"
+        out[first + i] = tuple(int(v) for v in r[:8]) + (int(r[8] or 0),)
+    # the launcher's switch instantiates exactly the table's rows
+    for cid, (bm, bn, wm, wn, kt, kg, d1, d9, pipe) in out.items():
+        assert f"case {cid}: return launch_ring_t<{bm}, {bn}, {wm}, {wn}, {kt}, {kg}, {d1}, {d9}{', true' if pipe else ''}>(g, s);" in src, cid
+    return out
+
+
 def test_tuned_table_entries_are_valid():
     ents = _entries()
     assert len(ents) >= 150
@@ -41,7 +59,19 @@ def test_tuned_table_entries_are_valid():
     src = open(HIP).read()
     first_sd, num_all = (int(v) for v in re.search(r"kFirstSdCfg = (\d+), kNumAllCfgs = (\d+)", src).groups())
     exists = lambda c: 4 <= c < 8 or 12 <= c < 16 or first_sd <= c < num_all  # noqa: E731  (cfg_exists)
+    ring = _ring_cfgs()
     for (m, n, k, ks, st, ups, cfg, split, kg, line) in ents:
+        if cfg in ring:   # the ring form: stride 1, no upsample, whole channel blocks per split, its own k-groups, LDS fit at 8x8
+            bm, bn, wm, wn, kt, rkg, d1, d9, _pipe = ring[cfg]
+            assert st == 1 and ups == 0 and ks in (1, 3) and (k // (ks * ks)) % 64 == 0, line
+            assert kg in (0, rkg), line
+            units = k // 64 // (9 if ks == 3 else 1)
+            assert 1 <= split <= units, line
+            if ks == 1 and n in (k, 3 * k, 8 * k):   # may carry a folded LayerNorm: K stays in one workgroup
+                assert split == 1, line
+            assert (d9 * rkg * kt * bn + 2 * ((bm + 2 * 8 + 2 + 7) & ~7) + 1) * 128 <= 160 * 1024, line
+            assert d1 * rkg * kt * (bn + bm) * 128 <= 160 * 1024, line
+            continue
         assert exists(cfg), line
         assert ks in (1, 3) and st in (1, 2) and ups in (0, 1), line
         assert k % (ks * ks) == 0, line

@@ -47,5 +47,5 @@ fam_tot = collections.Counter()
 for (fam, tag), a in agg.items():
     fam_tot[fam] += a[1]
 print(" ".join(f"{k}={v:.3f}ms" for k, v in fam_tot.items()))
-for (fam, tag), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+for (fam, tag), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{a[1] * 1e3:9.1f} us  x{a[0]:3d}  avg {a[1] * 1e3 / a[0]:7.1f} us  {a[2] / max(a[1], 1e-9) / 1e9:7.0f} TF  {fam:10s} {tag}")

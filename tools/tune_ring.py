@@ -126,15 +126,20 @@ for ln in lines:
             continue
         mt = (-(-(b2 * h * w) // c["bm"]) + -(-((B - b2) * h * w) // c["bm"])) if dual else -(-M // c["bm"])
         tiles = mt * -(-N // c["bn"])
-        if tiles > 2400:
+        if tiles > 8192:
             continue
         splits = [1] if tiles >= 96 else []
-        if act != 2:
+        # N in (K, 3K, 8K) on one source: possibly a folded-LayerNorm GEMM (q, q|k|v, GEGLU projection), which keeps K in one
+        # workgroup -- the table is keyed by shape only, so these shapes take split 1
+        ln_shape = ks == 1 and c1 == 0 and N in (K, 3 * K, 8 * K)
+        if ln_shape:
+            splits = [1]
+        elif act != 2:
             for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
                 if s <= units // 2 and 100 <= tiles * s <= 1100 and s * M * N * 4 <= ws.numel():
                     splits.append(s)
         if not splits:
-            splits = [max(1, min(units // 2, 128 // max(1, tiles)))] if act != 2 else [1]
+            splits = [max(1, min(units // 2, 128 // max(1, tiles)))] if (act != 2 and not ln_shape) else [1]
         for sp in sorted(set(splits)):
             try:
                 res.append((time_launch(launcher(cfg, sp, 0), args.reps), cfg, sp, c["kg"]))

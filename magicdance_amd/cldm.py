@@ -7,7 +7,8 @@ Mirrors (same names, ctor kwargs, call signatures, cond-dict keys, state-dict ke
   DiffusionWrapper                     ddpm.py:1313-1352 (only the 'crossattn' route the pose config uses)
   create_model / instantiate_from_config   cldm/model.py:24-28, ldm/util.py:72-87
 The YAML (configs/cldm_v15_reference_only_pose.yaml) differs from the reference's only in the four ``target:`` strings.
-VAE and CLIP are outside this round's scope: their configs are instantiated only when importable.
+The first stage (VAE) is this package's own ``autoencoder.AutoencoderKL`` on the same kernels; the text encoder
+ is the ``clip.FrozenCLIPEmbedder`` wrapper around stock transformers -- both named by the YAML's ``target:`` strings.
 """
 import importlib
 import os
@@ -266,9 +267,12 @@ class ControlLDMReferenceOnlyPose(nn.Module):
         until the next apply_model call)."""
         assert isinstance(cond, dict)
         app, pose_e, unet = self.engines()
-        cond_txt = torch.cat(cond["c_crossattn"], 1)
+        # (a one-element list -- every caller on this path -- is passed through AS the caller's tensor: the engines' context / hint
+        #  caches recognise it by identity + version, without the device -> host content comparison a fresh torch.cat copy needs)
+        cat1 = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 1)  # noqa: E731
+        cond_txt = cat1(cond["c_crossattn"])
         if self.control_enabled and cond.get("c_crossattn_void") is not None:
-            cond_txt_void = torch.cat(cond["c_crossattn_void"], 1)
+            cond_txt_void = cat1(cond["c_crossattn_void"])
         else:
             cond_txt_void = cond_txt
         x = x_noisy.detach().to(device=self.device, dtype=F32).contiguous()
@@ -282,7 +286,7 @@ class ControlLDMReferenceOnlyPose(nn.Module):
             banks = app.appearance(ref, app._t_dev(t, ref.shape[0]), app.context_kv(cond_txt_void))
         pose = None
         if self.has_pose and self.control_enabled and cond.get("c_concat") is not None and not uc:
-            hint = torch.cat(cond["c_concat"], 1)
+            hint = cat1(cond["c_concat"])
             pose = pose_e.pose(x, pose_e.hint_features(hint), t_dev, pose_e.context_kv(cond_txt_void))
         return unet.unet(x, t_dev, unet.context_kv(cond_txt), banks=None if uc else banks, pose=pose,
                          nread=0 if uc else b, only_mid_control=self.only_mid_control)

@@ -90,7 +90,8 @@ class DDIMSampler_ReferenceOnly(object):
         total_steps = timesteps.shape[0]
 
         if (not force_generic and ucg_schedule is None and noise_dropout == 0.
-                and self._fused_ok(cond, unconditional_conditioning, unconditional_guidance_scale)):
+                and self._fused_ok(cond, unconditional_conditioning, unconditional_guidance_scale)
+                and self._table_fits(cond, unconditional_conditioning, shape)):
             return self._fused_sampling(cond, img, unconditional_guidance_scale, callback, img_callback, log_every_t,
                                         intermediates, unconditional_conditioning)
 
@@ -195,6 +196,30 @@ class DDIMSampler_ReferenceOnly(object):
                     return False
         return float(np.abs(self.ddim_sigmas).max()) == 0.0
 
+    # Reference-KV table budget of the fused route.  The table holds, per DDIM step and per reference sample, the projected K / V^T
+    # of all 16 bank entries (46 MB fp16 at 512 x 512): 2.3 GB for the entry points' form (ONE shared reference, 50 steps).  The
+    # balance form keeps one reference row per sample of the 2b batch and the noisy form one per frame, so their tables grow with
+    # the batch (8 frames, balance: 37 GB).  Beyond the budget the per-call route runs instead (no table) -- same results.
+    TABLE_BUDGET_BYTES = int(float(os.environ.get("MD_TABLE_BUDGET_GB", "64")) * (1 << 30))
+
+    def _table_bytes(self, c, uc, shape):
+        from . import engine
+        from .nets import bank_shapes
+        b, _, hh, ww = shape
+        if uc is not None and uc.get("image_control") is not None:
+            bref = 2 * b                                  # balance
+        elif not c.get("wonoise", True):
+            bref = b                                      # noisy reference: one bank per frame
+        else:
+            ref = torch.cat(c["image_control"], 1)
+            bref = 1 if (ref.shape[0] == 1 or FusedStepRunner._same_rows(ref)) else ref.shape[0]
+        app = self.model.engines()[0]
+        row = sum(n * ch + ch * engine.kv_ld(n) for n, ch in bank_shapes(app.cfg, (hh, ww)))
+        return self.ddim_timesteps.shape[0] * bref * row * (1 if engine.ATTN_FP8 else 2)
+
+    def _table_fits(self, c, uc, shape):
+        return self._table_bytes(c, uc, shape) <= self.TABLE_BUDGET_BYTES
+
     def _fused_sampling(self, c, img, scale, callback, img_callback, log_every_t, intermediates, uc=None):
         model = self.model
         st = model._fused
@@ -252,7 +277,8 @@ class FusedStepRunner:
         self.tkey = None
         self.pose_stream = torch.cuda.Stream(device=model.device)
 
-    def _same_rows(self, t):
+    @staticmethod
+    def _same_rows(t):
         return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
 
     def plan_table(self, S, bref, world=1, sharded=None):
@@ -290,6 +316,7 @@ class FusedStepRunner:
         ref = torch.cat(c["image_control"], 1).detach().to(device=dev, dtype=F32)
         ctx = torch.cat(c["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
         rep = lambda t, n: t if t.shape[0] == n else t.expand(n, *t.shape[1:])  # noqa: E731
+        ref_orig = ref   # the reference at the batch the caller gave it (1, or one per frame): what q_sample draws its noise for
         if balance:
             ctx_u = torch.cat(uc["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
             base = rep(ref, b)     # (:529-551: both halves see the CONDITIONAL dict's reference; uc's only switches the branch)
@@ -362,12 +389,14 @@ class FusedStepRunner:
         self.ts_table.copy_(torch.from_numpy(np.repeat(steps[:, None], self.ts_table.shape[1], 1).copy()))
         self.coef_table.copy_(torch.from_numpy(coef))
         self.counter.zero_()
-        # noisy reference: q_sample(reference, t) per step, the noise drawn in step order exactly as the per-step route draws it
-        # (one randn_like(reference) per step, ddpm.py:356-359 through ddim.py:529-535) -- the table rows are built from these
+        # noisy reference: q_sample(reference, t) per step, the noise drawn in step order exactly as the per-step route draws it --
+        # ONE randn_like(cond_image_start) per step AT THE REFERENCE'S OWN BATCH (ddpm.py:356-359 through ddim.py:529-535): a batch-1
+        # reference shared by b frames gets one noise tensor per step, broadcast over the frames by the [b] timestep factors (and
+        # consumes one draw of its size from the RNG, not b) -- the table rows are built from these
         self.ref_rows = None
         if noisy:
             tl = torch.from_numpy(np.flip(sampler.ddim_timesteps).copy()).to(dev).long()
-            rows = [model.q_sample(base.contiguous(), tl[i].expand(b)) for i in range(S)]     # one [b, ...] draw per step
+            rows = [rep(model.q_sample(ref_orig.contiguous(), tl[i].expand(b)), b) for i in range(S)]
             self.ref_rows = torch.stack([torch.cat([r, r], 0) if balance else r for r in rows]).contiguous()
         # Time-embedding tables: timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers depend on the step only, not on
         # x or the frame: computed here for all S steps at once (same kernels, rows = steps), so that a step reads ONE row per

@@ -282,9 +282,95 @@ def run_vae_case(name):
     print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s", missing)
 
 
+ENVELOPE_CASES = {
+    # The reference's OWN fp16 arithmetic against its fp32 arithmetic, same weights / inputs: what `--use_fp16` costs the reference
+    # itself (test_any_image_pose.py:237 wraps sample_log in autocast; fp32 QK^T per attention.py:179-182, fp32 GroupNorm per
+    # util.py:252-254).  name: (net overrides, latent side, ddim steps, probe t, x_T scale, gain of the UNet's eps head)
+    "env16_small_b1_s50": (dict(model_channels=64, num_heads=2), 16, 50, 501, 1.0, 1.0),
+    "env16_c1_b1_s2": (dict(), 64, 2, 981, 1.0, 1.0),              # configs[1] geometry, first two steps
+    "env16_c1_b1_s50": (dict(), 64, 50, 981, 1.0, 1.0),            # configs[1] in full (fp32 side = tests/golden/c1_b1_s50.npz)
+    "env16_c1s_b1_s50": (dict(), 64, 50, 981, 1.0 / 16, 0.1),      # the realistic-latent-scale case (fp32 side = c1s_b1_s50.npz)
+}
+
+
+def run_envelope_case(name):
+    """Runs the unmodified reference twice on the same seeded weights / inputs -- plain fp32, and under
+    torch.autocast(cpu, float16) -- and stores both eps pairs and both x_t trajectories.  CPU autocast lowers the same op set the
+    reference's CUDA autocast does (conv / linear / bmm to fp16 operands with fp32 accumulation, fp16 activations between them);
+    the one place the reference opts out, `with torch.autocast(enabled=False, device_type='cuda')` around q k^T
+    (attention.py:179-182), names the cuda device type: it is mapped to the cpu device type for the duration of the run so that the
+    q k^T product is fp32 here exactly as it is on the reference's GPU path."""
+    geo, side, steps, t_probe, xt_scale, eps_gain = ENVELOPE_CASES[name]
+    torch.manual_seed(0)
+    t0 = time.time()
+    m = ref_shim.build_reference_model(geo, image_size=side)
+    sd = {}
+    for pre, mod in [(PREFIXES["unet"], m.model.diffusion_model), (PREFIXES["app"], m.appearance_control_model),
+                     (PREFIXES["pose"], m.pose_control_model)]:
+        sd.update(synthetic.synth_state_dict(mod, pre, seed=0))
+    if eps_gain != 1.0:
+        for k in ("weight", "bias"):
+            sd[PREFIXES["unet"] + "out.2." + k] = sd[PREFIXES["unet"] + "out.2." + k] * eps_gain
+    m.load_state_dict(sd, strict=False)
+    del sd
+    inp = synthetic.synth_inputs((side, side), frames=1, seed=0)
+    x_T = inp["x_T"] * xt_scale
+    ref, ctx, pose = inp["ref"], inp["ctx"], inp["pose"]
+    c = {"c_concat": [pose], "c_crossattn": [ctx], "image_control": [ref], "wonoise": True, "overlap_sampling": False}
+    uc = {"c_concat": [pose], "c_crossattn": [ctx], "wonoise": True, "overlap_sampling": False}
+    t = torch.full((1,), t_probe, dtype=torch.long)
+    out = dict(geo_model_channels=geo.get("model_channels", 320), geo_num_heads=geo.get("num_heads", 8), side=side, frames=1,
+               t_probe=t_probe, steps=steps, seed=0, xt_scale=xt_scale, eps_gain=eps_gain, x_T=x_T.numpy(), ref=ref.numpy())
+    fp32_file = {"env16_c1_b1_s50": "c1_b1_s50", "env16_c1s_b1_s50": "c1s_b1_s50"}.get(name)   # fp32 side already on disk
+
+    def run(tag):
+        with torch.no_grad():
+            out["eps_c_" + tag] = m.apply_model(x_T, t, c, ref).float().numpy()
+            out["eps_u_" + tag] = m.apply_model(x_T, t, c, None, uc=True).float().numpy()
+            z, inter = m.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
+                                    unconditional_conditioning=uc, inpaint=None, x_T=x_T, log_every_t=1)
+            out["x_traj_" + tag] = torch.stack([x.float() for x in inter["x_inter"]]).numpy()
+        print(f"[golden] {name}: {tag} run done {time.time() - t0:.0f}s", flush=True)
+
+    if fp32_file is None:
+        run("fp32")
+    else:
+        g = np.load(os.path.join(GOLDEN_DIR, fp32_file + ".npz"))
+        assert np.array_equal(g["x_T"], x_T.numpy()) and float(g["eps_gain"]) == eps_gain
+        out["eps_c_fp32"], out["eps_u_fp32"], out["x_traj_fp32"] = g["eps_c"], g["eps_u"], g["x_traj"]
+    real_autocast = torch.autocast
+
+    class cuda_as_cpu(real_autocast):   # (a subclass: torch.autocast is used as a context manager class)
+        def __init__(self, device_type=None, *a, **k):
+            super().__init__("cpu" if device_type == "cuda" else device_type, *a, **k)
+    torch.autocast = cuda_as_cpu
+    try:
+        with real_autocast("cpu", dtype=torch.float16):
+            run("fp16")
+    finally:
+        torch.autocast = real_autocast
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+    per_step = [rel(out["x_traj_fp16"][i], out["x_traj_fp32"][i]) for i in range(1, steps + 1)]
+    out["latent_rel_per_step"] = np.array(per_step)
+    summary = dict(eps_c=rel(out["eps_c_fp16"], out["eps_c_fp32"]), eps_u=rel(out["eps_u_fp16"], out["eps_u_fp32"]),
+                   latent_final_rel=per_step[-1], latent_final_abs=float(np.abs(out["x_traj_fp16"][-1] - out["x_traj_fp32"][-1]).max()),
+                   latent_max=float(np.abs(out["x_traj_fp32"][-1]).max()))
+    out.update({"env_" + k: v for k, v in summary.items()})
+    if fp32_file is not None:   # the fp32 side stays in its own fixture: store the fp16 side only (plus the deviations)
+        for k in ("eps_c_fp32", "eps_u_fp32", "x_traj_fp32"):
+            del out[k]
+        out["fp32_fixture"] = np.array(fp32_file)
+        out["x_traj_fp16"] = out["x_traj_fp16"].astype(np.float16 if False else np.float32)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) in {time.time() - t0:.1f}s  {summary}", flush=True)
+
+
 if __name__ == "__main__":
     for n in (sys.argv[1:] or list(CASES) + list(VARIANT_CASES) + list(VAE_CASES)):
-        if n in VAE_CASES:
+        if n in ENVELOPE_CASES:
+            run_envelope_case(n)
+        elif n in VAE_CASES:
             run_vae_case(n)
         elif n in VARIANT_CASES:
             run_variant_case(n)

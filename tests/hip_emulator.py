@@ -145,9 +145,9 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
         for b in range(batch):
             kb = dec(k0, (batch, heads, n0, d), (k0_bs, d, ld_k0, 1))[b]
             vb = dec(vt0, (batch, heads, n0, d), (vt0_bs, d * ld_vt0, 1, ld_vt0))[b]
-            if k1 is not None and b < n1_batches:
-                kb = torch.cat([kb, dec(k1, (batch, heads, n1, d), (k1_bs, d, ld_k1, 1))[b]], 1)
-                vb = torch.cat([vb, dec(vt1, (batch, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1))[b]], 1)
+            if k1 is not None and b < n1_batches:   # (the bank segment holds n1_batches samples, or one shared one: stride 0)
+                kb = torch.cat([kb, dec(k1, (n1_batches, heads, n1, d), (k1_bs, d, ld_k1, 1))[b]], 1)
+                vb = torch.cat([vb, dec(vt1, (n1_batches, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1))[b]], 1)
             s2 = torch.einsum("hid,hjd->hij", qq[b], kb)
             p = torch.exp2(s2 - s2.max(-1, keepdim=True).values)
             o[b].copy_(torch.einsum("hij,hjd->hid", _from_e4m3(_to_e4m3(p)), vb) / p.sum(-1, keepdim=True))
@@ -159,8 +159,8 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
     for b in range(batch):
         kb, vb = kk[b], vv[b]
         if k1 is not None and b < n1_batches:
-            k1b = _mem(k1, (batch, heads, n1, d), (k1_bs, d, ld_k1, 1)).float()[b]
-            v1b = _mem(vt1, (batch, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1)).float()[b]
+            k1b = _mem(k1, (n1_batches, heads, n1, d), (k1_bs, d, ld_k1, 1)).float()[b]   # only n1_batches samples exist there
+            v1b = _mem(vt1, (n1_batches, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1)).float()[b]
             kb, vb = torch.cat([kb, k1b], 1), torch.cat([vb, v1b], 1)
         s = torch.einsum("hid,hjd->hij", qq[b], kb) * scale
         o[b].copy_(torch.einsum("hij,hjd->hid", s.softmax(-1), vb))

@@ -239,6 +239,65 @@ def test_wonoise_false_route_matches_reference_golden(monkeypatch, route):
     assert torch.allclose(type(model).q_sample(model, x0, t, noise=n), want, atol=1e-6)
 
 
+def test_wonoise_false_shared_reference_draws_one_noise_per_step(monkeypatch):
+    """b = 2 frames sharing a batch-1 image_control with wonoise=False: the reference draws randn_like(cond_image_start) at the
+    reference's OWN batch (ddim.py:529-535, ddpm.py:356-359) -- one noise tensor per step, broadcast over the frames -- on the
+    generic route; the fused route must draw the same way (same RNG consumption, same result)."""
+    hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
+    from magicdance_amd import synthetic
+    model = H.build_hip_model(64, 2, seed=0, device="cpu", image_size=8)
+    inp = synthetic.synth_inputs((8, 8), frames=2, seed=3)
+    ctx = inp["ctx"].repeat(2, 1, 1)
+    c = {"c_concat": [inp["pose"]], "c_crossattn": [ctx], "image_control": [inp["ref"]], "wonoise": False, "overlap_sampling": False}
+    uc = {"c_concat": [inp["pose"]], "c_crossattn": [ctx], "wonoise": False, "overlap_sampling": False}
+    x_T = inp["x_T"].repeat(2, 1, 1, 1)
+    assert inp["ref"].shape[0] == 1
+    outs, draws = {}, {}
+    for route in ("fused", "generic"):
+        shapes = []
+        orig = type(model).q_sample
+
+        def spy(x_start, t, noise=None, _orig=orig, _shapes=shapes):
+            _shapes.append(tuple(x_start.shape))
+            return _orig(model, x_start, t, noise=noise)
+        monkeypatch.setattr(model, "q_sample", spy, raising=False)
+        model._fused = None
+        torch.manual_seed(123)
+        z, _ = model.sample_log(cond=c, batch_size=2, ddim=True, ddim_steps=4, eta=0.0, unconditional_guidance_scale=7,
+                                unconditional_conditioning=uc, inpaint=None, x_T=x_T, force_generic=(route == "generic"))
+        assert (model._fused is not None) == (route == "fused")
+        outs[route], draws[route] = z, (shapes, torch.rand(1).item())   # (the next draw: both routes left the RNG in the same state)
+    assert all(s[0] == 1 for s in draws["fused"][0]) and len(draws["fused"][0]) == 4          # one batch-1 draw per step
+    assert draws["fused"][1] == draws["generic"][1]
+    assert _rel(outs["fused"].numpy(), outs["generic"].numpy()) <= 6e-3
+
+
+def test_fused_route_falls_back_when_the_table_does_not_fit(monkeypatch):
+    """the balance / noisy forms keep one reference row per sample: beyond the table budget the sampler takes the per-call route
+    (no table) instead of allocating tens of GB -- same result"""
+    hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
+    from magicdance_amd import ddim
+    g = H.load_golden("small_b1")
+    model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu", image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    smp = ddim.DDIMSampler_ReferenceOnly(model)
+    smp.make_schedule(int(g["steps"]), ddim_eta=0.0, verbose=False)
+    shape = tuple(inp["x_T"].shape)
+    one = smp._table_bytes(inp["c"], inp["uc"], shape)
+    assert smp._table_bytes(dict(inp["c"], wonoise=False), inp["uc"], (4,) + shape[1:]) == 4 * one            # noisy: per frame
+    assert smp._table_bytes(inp["c"], inp["uc_balance"], (4,) + shape[1:]) == 8 * one                          # balance: per sample of 2b
+    kw = dict(cond=inp["c"], batch_size=1, ddim=True, ddim_steps=int(g["steps"]), eta=0.0, unconditional_guidance_scale=7,
+              unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"])
+    z_f, _ = model.sample_log(**kw)
+    assert model._fused is not None
+    model._fused = None
+    monkeypatch.setattr(ddim.DDIMSampler_ReferenceOnly, "TABLE_BUDGET_BYTES", one - 1)
+    z_g, _ = model.sample_log(**kw)
+    assert model._fused is None and _rel(z_g.numpy(), z_f.numpy()) <= 1e-2
+
+
 def test_overlap_sampling_route_matches_reference_golden(monkeypatch):
     """overlap_sampling temporal windows (ddim.py:569-594), generic route, python-random offsets seeded as in the fixture."""
     import random

@@ -303,13 +303,22 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
 // busy).  Per tile t the wave runs two branch-free blocks:
 //   A: S^T(t+1) = K(t+1) Q^T  (MFMA)   interleaved with   P(t) = exp2(S(t) c - m)  -> fp16 (VALU / transcendental)
 //   B: O^T += V^T(t) P^T(t)    (MFMA)   interleaved with   row max of S(t+1), new running max, rescale factor (VALU)
-// i.e. the exponentials of tile t hide under the QK^T of tile t+1 and the max of tile t+1 under the PV of tile t.  K tiles run
-// one tile ahead of V tiles in their own 2-slot rings; one vmcnt(0) + barrier per tile as in v2.
+// i.e. the exponentials of tile t sit between the QK^T MFMAs of tile t+1 and the max of tile t+1 between the PV MFMAs of tile t.
+// K tiles run one tile ahead of V tiles in their own 2-slot rings; one vmcnt(0) + barrier per tile as in v2.
+// Round 4 (steady loop below; profiles/round4_attention_loop_ab.txt, round4_attention_pmc_d40.txt, round4_pipe_bench.txt): the
+// loop's scalar / bookkeeping work is gone -- load streams with their own descriptor + offset state, DMA issue behind the first
+// MFMAs of a tile, two tiles per trip with the score arrays swapping roles, -m as the C operand of the first k-step, the row max
+// exchanged across lane groups by v_permlane16/32_swap under the last PV MFMAs: 82 VALU + 35 SALU per tile instead of 123 + 60,
+// 44.9 % -> 51.8 % MFMA busy at 16 samples (d = 40), 693 -> 761 TFLOP/s; one-frame shape 549 -> 654.  What remains is the floor of
+// this instruction mix on one SIMD: v_exp_f32 (9 cycles each, 32 per wave and tile) does not overlap with MFMAs of the same SIMD,
+// within a wave or across waves (pipe_bench: 28 MFMA + 32 exp + plain VALU = 431 ns per wave-tile whatever the occupancy = 59 %
+// busy; the kernel runs 441 ns), v_mfma_f32_16x16x16_f16 costs the same 16 cycles as 16x16x32 (no gain from a K = 32 + 16 split of
+// d = 40), and exp2 as a packed-fp16 polynomial on the plain VALU serialises with the MFMAs just the same (built, measured, removed).
 // Softmax denominator: where D is not a multiple of 16 (d = 40) the last 16-row fragment of O^T has free rows; row D of the V^T
 // tile in LDS is preset to ones (its DMA is skipped), so O^T[D][q] accumulates sum_kv P -- the row sum comes out of the PV MFMAs
 // (summing exactly the fp16 P that the numerator uses) and the per-score v_add disappears; otherwise the sum stays on the VALU.
 template <int D, int QF, int P>
-__global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
+__global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel_v3(const AttnArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DK = (D + 31) / 32 * 32;
   constexpr int KSTEPS = DK / 32;
@@ -371,27 +380,36 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(v1p), 0, (g.vt1 ? g.heads * D * g.ld_vt1 : 0) * 2, 0x00020000);
   unsigned ko0[KJ], ko1[KJ], vo0[VJ], vo1[VJ];
   int krow_[KJ], vkv_[VJ];
-#pragma unroll
-  for (int j = 0; j < KJ; ++j) {
-    const int i = j * 256 + tid;
+  // per-lane source offsets of this thread's DMA slots (functions of the thread id only): the round-4 loop keeps just the current
+  // segment's set alive and recomputes the rest behind an opaque copy of the thread id (12 registers less across the loop)
+  auto k_lane = [&](int tid_, int j, int ld, int& row) {
+    const int i = j * 256 + tid_;
     const int r = i / CL, pos = i % CL;
     const int gr = 4 * ((r >> 3) & 3) + (r & 3);
     const int sc = (pos - KM * gr) & (CL - 1);
-    const bool ok = sc * 8 < D;
-    krow_[j] = r;
-    ko0[j] = ok ? (unsigned)(r * g.ld_k0 + h * D + sc * 8) * 2u : OOB;
-    ko1[j] = ok ? (unsigned)(r * g.ld_k1 + h * D + sc * 8) * 2u : OOB;
-  }
-#pragma unroll
-  for (int j = 0; j < VJ; ++j) {
-    const int i = j * 256 + tid;
+    row = r;
+    return (sc * 8 < D) ? (unsigned)(r * ld + h * D + sc * 8) * 2u : OOB;
+  };
+  auto v_lane = [&](int tid_, int j, int ld, int& kv) {
+    const int i = j * 256 + tid_;
     const int r = i >> 3, pos = i & 7;
     const int sc = (pos - r) & 7;
-    const bool ok = r < D;
-    vkv_[j] = sc * 8;
-    vo0[j] = ok ? (unsigned)((h * D + r) * g.ld_vt0 + sc * 8) * 2u : OOB;
-    vo1[j] = ok ? (unsigned)((h * D + r) * g.ld_vt1 + sc * 8) * 2u : OOB;
-  }
+    kv = sc * 8;
+    return (r < D) ? (unsigned)((h * D + r) * ld + sc * 8) * 2u : OOB;
+  };
+  auto lane_offsets = [&](int tid_) {
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      ko0[j] = k_lane(tid_, j, g.ld_k0, krow_[j]);
+      ko1[j] = k_lane(tid_, j, g.ld_k1, krow_[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      vo0[j] = v_lane(tid_, j, g.ld_vt0, vkv_[j]);
+      vo1[j] = v_lane(tid_, j, g.ld_vt1, vkv_[j]);
+    }
+  };
+  lane_offsets(tid);
 
   // Tile order: the FULL 64-key tiles of segment 0, then those of segment 1 (software-pipelined loop, no masking), then the
   // partial last tile of either segment (sequential path below) -- softmax does not care about the order of the keys.
@@ -435,22 +453,6 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
   // instruction keeps live lanes, the copy lands in a free slot and is never used)
   auto issue_full_k = [&](int t) { const int tt = min(t, nfull - 1); issue_k(true, tt >= nf0, (tt >= nf0 ? tt - nf0 : tt) << 6, slot_of(t)); };
   auto issue_full_v = [&](int t) { issue_v(true, t >= nf0, (t >= nf0 ? t - nf0 : t) << 6, slot_of(t)); };
-  // this wave's DMA instructions per load group {K tile, V tile}: V instructions whose 8 rows lie beyond D are not issued
-  int lpt = KJ;
-#pragma unroll
-  for (int j = 0; j < VJ; ++j) lpt += ((j * 4 + wave) * 8 < D) ? 1 : 0;
-  auto wait_steady = [&]() {   // all but the newest P-1 load groups of this wave have landed (immediate operand: dispatch on the count)
-    const int n = (P - 1) * lpt;
-    if (P == 1 || n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define MD_VMCNT_CASE(N) else if (n == (N)) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
-    MD_VMCNT_CASE(2) MD_VMCNT_CASE(3) MD_VMCNT_CASE(4) MD_VMCNT_CASE(5) MD_VMCNT_CASE(6) MD_VMCNT_CASE(7) MD_VMCNT_CASE(8) MD_VMCNT_CASE(9)
-    MD_VMCNT_CASE(10) MD_VMCNT_CASE(11) MD_VMCNT_CASE(12) MD_VMCNT_CASE(13) MD_VMCNT_CASE(14) MD_VMCNT_CASE(15) MD_VMCNT_CASE(16)
-    MD_VMCNT_CASE(18) MD_VMCNT_CASE(20) MD_VMCNT_CASE(21) MD_VMCNT_CASE(22) MD_VMCNT_CASE(24) MD_VMCNT_CASE(26) MD_VMCNT_CASE(27)
-    MD_VMCNT_CASE(30) MD_VMCNT_CASE(33) MD_VMCNT_CASE(36) MD_VMCNT_CASE(39)
-#undef MD_VMCNT_CASE
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a count without a case: drain (always correct)
-  };
-
   if constexpr (ONES) {  // rows D .. DF*16-1 of both V slots: row D = ones, the rest zeros (128 B per row, any chunk order)
     static_assert(D % 8 == 0, "preset rows start on a DMA instruction boundary (8 rows)");
     constexpr int NPRE = (DF * 16 - D) * 8;   // 16-byte chunks per slot
@@ -610,31 +612,114 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
       }
       first = false;
     }
-    for (int t = 0; t + 1 < nfull; ++t) {
-      // K(t+1) and V(t) have landed for every wave (counted wait: the P-1 newer groups stay in flight -- one L2 / Infinity-Cache
-      // round trip takes longer than the MFMAs of one tile, so with a single tile of prefetch every iteration waited for its
-      // loads); the slots of K(t) (its S^T is in registers) and V(t-1) are free.  Near the end fewer groups are in flight: drain.
-      if (t + P <= nfull) wait_steady(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ONE branch-free block whose instruction order is PINNED step by step (left alone, hipcc emits all exponentials first
-      // and all MFMAs after them: no overlap inside the wave).  A: every QK^T MFMA of tile t+1 is followed by its share of the
-      // exponentials of tile t (a pair of scores -> fma, exp2, cvt_pk); the K fragments are read up front.  B: every PV MFMA of
-      // tile t is followed by a slice of the row-max chain of tile t+1.
-      h8 pf[QF][2];
-      f4 st2[QF][4];
-      float mx[QF];
+    {
+      // ---- the steady loop (round-4 form; P = 1) ---------------------------------------------------------------------------
+      //  * the two load streams (K two tiles ahead, V^T one) keep their descriptor / per-lane offsets / scalar offset as loop state
+      //    and switch segment under a uniform branch: the per-tile tile -> (segment, offset) arithmetic and the per-row validity
+      //    selects of the generic issue functions are gone (full tiles are in range by construction);
+      //  * their LDS-DMA instructions are issued BEHIND the first QK^T MFMAs of the tile, not between the barrier and them;
+      //  * two tiles per loop trip with the score arrays swapping roles (no register copies at the back edge), the first k-step of
+      //    every S^T fragment takes -m as its C operand (no accumulator initialisation);
+      //  * the row maximum crosses the lane groups by v_permlane16_swap / v_permlane32_swap (VALU) under the last PV MFMAs
+      //    instead of two dependent ds_bpermute round trips after them.
+      static_assert(P == 1, "the round-4 loop drains its loads every tile (one tile of prefetch)");
+      constexpr int NA = 4 * KSTEPS * QF;      // MFMAs of A
+      constexpr int NP = 8 * QF;               // score pairs of a tile
+      constexpr int NB = DF * 2 * QF;          // MFMAs of B
+      constexpr int NX = 8 * QF;               // v_max3 steps of the row-max chains
+      constexpr int VEARLY = ((D == 40 && QF == 2) || D == 80) ? 0 : 1;   // (a longer lead costs DF * 8 registers = a wave per SIMD there)
+      constexpr int NB1 = NB >= 6 ? NB - 4 : (NB + 1) / 2;   // the chains finish under the first NB1 PV MFMAs, the lane-group exchange
+                                                             // under the last 4 (a short block B -- test geometries -- finishes it behind them)
+      __amdgpu_buffer_rsrc_t kd = rk0, vd = rv0;
+      unsigned kvo[KJ], vvo[VJ];
+      unsigned k_soff, v_soff, k_step;
+      int k_tile = 2, v_tile = 1, k_left, v_left;
+      int tid_l = tid;
+      asm volatile("" : "+v"(tid_l));   // (opaque: the offsets below must not be merged with the sets computed at kernel entry)
+      [[maybe_unused]] int unused_row;
       {
-        const char* Ks = Kring + slot_of(t + 1) * KBYTES;
-        const char* Vs = Vring + slot_of(t) * VBYTES;
-        // (an A/B with the K fragment reads ahead of this issue block and the V^T reads half-way through block A measured no
-        // gain, profiles/round3_attention_order_ab.txt: the tile loop is not bound by the LDS latency at its head)
-        h8 kfr[4][KSTEPS];
-        if (t + P < nfull) {
-          issue_full_k(t + 1 + P);
-          issue_full_v(t + P);
-          __builtin_amdgcn_sched_barrier(0);
+        const bool ks1 = k_tile >= nf0, vs1 = v_tile >= nf0;
+        kd = ks1 ? rk1 : rk0;
+        vd = vs1 ? rv1 : rv0;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) kvo[j] = k_lane(tid_l, j, ks1 ? g.ld_k1 : g.ld_k0, unused_row);
+#pragma unroll
+        for (int j = 0; j < VJ; ++j) vvo[j] = v_lane(tid_l, j, vs1 ? g.ld_vt1 : g.ld_vt0, unused_row);
+        k_step = (unsigned)(64 * (ks1 ? g.ld_k1 : g.ld_k0)) * 2u;
+        k_soff = (unsigned)(ks1 ? k_tile - nf0 : k_tile) * k_step;
+        v_soff = (unsigned)(vs1 ? v_tile - nf0 : v_tile) * 128u;
+        k_left = (ks1 ? nfull : nf0) - k_tile;
+        v_left = (vs1 ? nfull : nf0) - v_tile;
+      }
+      auto stream_k = [&]() {   // K(k_tile) -> slot k_tile & 1; then advance
+        if (k_tile < nfull) {
+          char* Ks = Kring + (k_tile & 1) * KBYTES;
+#pragma unroll
+          for (int j = 0; j < KJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kd, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16, kvo[j], k_soff, 0, 0);
         }
+        ++k_tile;
+        k_soff += k_step;
+        if (--k_left == 0) {   // (uniform) the stream enters the bank segment
+          kd = rk1;
+#pragma unroll
+          for (int j = 0; j < KJ; ++j) kvo[j] = k_lane(tid_l, j, g.ld_k1, unused_row);
+          k_step = (unsigned)(64 * g.ld_k1) * 2u;
+          k_soff = 0u;
+        }
+      };
+      auto stream_v = [&]() {
+        if (v_tile < nfull) {
+          char* Vs = Vring + (v_tile & 1) * VBYTES;
+#pragma unroll
+          for (int j = 0; j < VJ; ++j) {
+            if ((j * 4 + wave) * 8 >= D) continue;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vd, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16, vvo[j], v_soff, 0, 0);
+          }
+        }
+        ++v_tile;
+        v_soff += 128u;
+        if (--v_left == 0) {
+          vd = rv1;
+#pragma unroll
+          for (int j = 0; j < VJ; ++j) vvo[j] = v_lane(tid_l, j, g.ld_vt1, unused_row);
+          v_soff = 0u;
+        }
+      };
+      auto vmax = [](float a, float b2) {   // plain v_max_f32 (fmaxf puts a canonicalising v_max in front of each operand)
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2));
+        return r;
+      };
+      typedef unsigned u2v __attribute__((ext_vector_type(2)));
+      // the row maximum across the four lane groups of a query column, in four VALU stages (0: exchange lane groups g <-> g ^ 1,
+      // 1: max, 2: exchange wave halves, 3: max)
+      auto exchange_stage = [&](int stg, float (&mx)[QF], float (&mo)[QF]) {
+#pragma unroll
+        for (int f2 = 0; f2 < QF; ++f2) {
+          if (stg == 0) {
+            const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx[f2]), __float_as_uint(mx[f2]), false, false);
+            mx[f2] = __uint_as_float(r[0]);
+            mo[f2] = __uint_as_float(r[1]);
+          } else if (stg == 2) {
+            const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[f2]), __float_as_uint(mx[f2]), false, false);
+            mx[f2] = __uint_as_float(r[0]);
+            mo[f2] = __uint_as_float(r[1]);
+          } else {
+            mx[f2] = vmax(mx[f2], mo[f2]);
+          }
+        }
+      };
+      // one tile: sc = scores of tile t (relative to the running max), sn <- scores of tile t + 1
+      auto tile_step = [&](int t, f4 (&sc)[QF][4], f4 (&sn)[QF][4]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1) and V(t) have landed (this wave's share); every wave is done with
+        __builtin_amdgcn_s_barrier();                      // the slots of K(t) and V(t-1)
+        __builtin_amdgcn_sched_barrier(0);
+        h8 pf[QF][2];
+        float mx[QF];
+        const char* Ks = Kring + ((t + 1) & 1) * KBYTES;
+        const char* Vs = Vring + (t & 1) * VBYTES;
+        h8 kfr[4][KSTEPS];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
           const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
@@ -642,38 +727,38 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int ks = 0; ks < KSTEPS; ++ks)
             kfr[kf][ks] = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < QF; ++f)
-#pragma unroll
-          for (int kf = 0; kf < 4; ++kf) st2[f][kf] = negm[f];
         [[maybe_unused]] float ps[QF];
 #pragma unroll
         for (int f = 0; f < QF; ++f) ps[f] = 0.f;
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int NA = 4 * KSTEPS * QF;      // MFMAs of A
-        constexpr int NP = 8 * QF;               // score pairs of tile t
         h8 vfr[DF][2];
-        auto read_v = [&]() {
-#pragma unroll
-          for (int i = 0; i < DF; ++i) {
-            const int row = i * 16 + lr;
-#pragma unroll
-            for (int pk = 0; pk < 2; ++pk) vfr[i][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
-          }
-        };
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           const int kf = i / (KSTEPS * QF), ks = (i / QF) % KSTEPS, f = i % QF;
-          st2[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], st2[f][kf], 0, 0, 0);
+          if (ks == 0)
+            sn[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], negm[f], 0, 0, 0);
+          else
+            sn[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], sn[f][kf], 0, 0, 0);
 #pragma unroll
-          for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs
+          for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs of tile t
             const int pf_ = pp / 8, pkf = (pp % 8) / 2, pr = (pp % 2) * 2;
-            const float p0 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr]);
-            const float p1 = __builtin_amdgcn_exp2f(st[pf_][pkf][pr + 1]);
+            const float p0 = __builtin_amdgcn_exp2f(sc[pf_][pkf][pr]);
+            const float p1 = __builtin_amdgcn_exp2f(sc[pf_][pkf][pr + 1]);
             if constexpr (!ONES) ps[pf_] += p0 + p1;
             pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr] = (half_t)p0;
             pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr + 1] = (half_t)p1;
+          }
+          if (i == 1) {   // the next tiles' loads leave behind the first MFMAs
+            stream_k();
+            stream_v();
+          }
+          if (i == NA - 1 - VEARLY) {   // V^T fragments of tile t: requested under the last MFMAs of block A
+#pragma unroll
+            for (int di = 0; di < DF; ++di) {
+              const int row = di * 16 + lr;
+#pragma unroll
+              for (int pk = 0; pk < 2; ++pk) vfr[di][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -682,37 +767,47 @@ __global__ __launch_bounds__(256) void attn_kernel_v3(const AttnArgs g) {
           for (int f = 0; f < QF; ++f) l_run[f] += ps[f];
         }
         // B
-        read_v();
 #pragma unroll
         for (int f = 0; f < QF; ++f) mx[f] = -INFINITY;
+        float mo[QF];
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int NB = DF * 2 * QF;          // MFMAs of B
-        constexpr int NX = 8 * QF;               // v_max3 steps of the row-max chains (two scores each)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int di = i / (2 * QF), pk = (i / QF) % 2, f = i % QF;
           o[di][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[di][pk], pf[f][pk], o[di][f], 0, 0, 0);
+          {
+            if (i < NB1) {
 #pragma unroll
-          for (int x = (i * NX) / NB; x < ((i + 1) * NX) / NB; ++x) {
-            const int xf = x / 8, xe = (x % 8) * 2;
-            mx[xf] = max3(mx[xf], st2[xf][xe >> 2][xe & 3], st2[xf][xe >> 2][(xe & 3) + 1]);
+              for (int x = (i * NX) / NB1; x < ((i + 1) * NX) / NB1; ++x) {
+                const int xf = x % QF, xe = (x / QF) * 2;   // the chains of the QF columns alternate: consecutive steps are independent
+                mx[xf] = max3(mx[xf], sn[xf][xe >> 2][xe & 3], sn[xf][xe >> 2][(xe & 3) + 1]);
+              }
+            } else if (i - NB1 < 4) {
+              exchange_stage(i - NB1, mx, mo);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int f = 0; f < QF; ++f) {
-          float v = mx[f];
-          v = fmaxf(v, __shfl_xor(v, 16, 64));
-          v = fmaxf(v, __shfl_xor(v, 32, 64));
-          mx[f] = v;
-        }
+        for (int stg = NB - NB1; stg < 4; ++stg) exchange_stage(stg, mx, mo);
+        __builtin_amdgcn_sched_barrier(0);
+        rescale_to(mx, sn, THR);
+      };
+      f4 sb[QF][4];
+      int t = 0;
+      for (; t + 2 < nfull; t += 2) {
+        tile_step(t, st, sb);
+        tile_step(t + 1, sb, st);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      rescale_to(mx, st2, THR);
+      if (t + 1 < nfull) {
+        tile_step(t, st, sb);
 #pragma unroll
-      for (int f = 0; f < QF; ++f)
+        for (int f = 0; f < QF; ++f)
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) st[f][kf] = st2[f][kf];
+          for (int kf = 0; kf < 4; ++kf) st[f][kf] = sb[f][kf];
+      }
+      asm volatile("" : "+v"(tid_l));
+      lane_offsets(tid_l);   // the partial-tile path below uses the generic issue functions
     }
     {  // last full tile: its V was issued in the previous iteration (or in the prologue)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -14,6 +14,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -54,7 +55,7 @@ __device__ __forceinline__ unsigned exp2_pair(float s0, float s1) {
 // interleaved with 32 exp + 16 cvt_pk, as attn_kernel_v3 pins them), 4 = 16 MFMA 16x16x16, 5 = 32 v_exp_f32 only,
 // 6 = 16 v_max3 + 16 cvt_pk (plain VALU), 7 = block A + block B (12 MFMA + 16 max3): a whole tile without memory
 template <int ROLE>
-__device__ __forceinline__ void body(int iters, f4 (&acc)[8], h8 (&a)[2], h8 (&b)[2], float (&x)[32], unsigned (&pk)[16]) {
+__device__ __forceinline__ void body(int iters, f4 (&acc)[8], h8 (&a)[2], h8 (&b)[2], float (&x)[32], unsigned (&pk)[16], f16v (&big)[4]) {
   for (int it = 0; it < iters; ++it) {
     if constexpr (ROLE == 1) {
 #pragma unroll
@@ -92,6 +93,43 @@ __device__ __forceinline__ void body(int iters, f4 (&acc)[8], h8 (&a)[2], h8 (&b
         pk[i] = r;
       }
       x[0] = m * 0.999f;
+    } else if constexpr (ROLE == 12) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) big[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], b[(i >> 1) & 1], big[i & 3], 0, 0, 0);
+    } else if constexpr (ROLE == 13 || ROLE == 14) {
+      // the same work as block A / the tile on the 32 x 32 x 16 MFMA (32 cycles each): 4 exp2 + 2 cvt_pk behind every MFMA
+      constexpr int NM = ROLE == 13 ? 8 : 6;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        big[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], b[(i >> 1) & 1], big[i & 3], 0, 0, 0);
+        constexpr int PER = 32 / NM;   // exps per MFMA (5 + remainder for 6 MFMAs)
+#pragma unroll
+        for (int e = i * PER; e < (i == NM - 1 ? 32 : (i + 1) * PER); e += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(x[e]), p1 = __builtin_amdgcn_exp2f(x[e + 1]);
+          unsigned r;
+          asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(p0), "v"(p1));
+          pk[e >> 1] = r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (ROLE == 14) {
+        float m = -1e30f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          h8 pb;
+          __builtin_memcpy(&pb, &pk[(i & 3) * 4], 16);
+          big[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], pb, big[i & 3], 0, 0, 0);
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(x[4 * i]), "v"(x[4 * i + 1]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(x[4 * i + 2]), "v"(x[4 * i + 3]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        x[0] = fminf(m, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * i + r] = -fabsf(big[i][r]) * 1e-3f;
+      }
     } else if constexpr (ROLE == 8) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -164,13 +202,17 @@ __global__ void pipe_kernel(int iters, long long* ticks, float* sink) {
   for (int i = 0; i < 16; ++i) pk[i] = 0x3c003c00u;
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
-  if (role_slot == 0) body<R0>(iters, acc, a, b, x, pk);
-  else if (role_slot == 1) body<R1>(iters, acc, a, b, x, pk);
-  else body<R2>(iters, acc, a, b, x, pk);
+  f16v big[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) big[i][r] = 0.f;
+  if (role_slot == 0) body<R0>(iters, acc, a, b, x, pk, big);
+  else if (role_slot == 1) body<R1>(iters, acc, a, b, x, pk, big);
+  else body<R2>(iters, acc, a, b, x, pk, big);
   const long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   for (int i = 0; i < 32; ++i) s += x[i];
+  for (int i = 0; i < 4; ++i) s += big[i][0] + big[i][5] + big[i][15];
   for (int i = 0; i < 16; ++i) s += (float)pk[i];
   if (s == 12345.678f) sink[0] = s;
   if (lane == 0) ticks[blockIdx.x * 16 + wave] = t1 - t0;
@@ -228,6 +270,14 @@ int main() {
   run<7, 7, 7>("3 waves/SIMD: tile + tile + tile", 3, N, d_ticks, d_sink);
   run<1, 5, 5>("3 waves/SIMD: mfma + 32 exp + 32 exp", 3, N, d_ticks, d_sink);
   run<3, 3, 3>("3 waves/SIMD: block A x 3", 3, N, d_ticks, d_sink);
+  run<12, 0, 0>("1 wave/SIMD: 8 x mfma 32x32x16", 1, N, d_ticks, d_sink);
+  run<13, 0, 0>("1 wave/SIMD: block A on 32x32x16 (8 mfma | 32 exp, 16 cvt)", 1, N, d_ticks, d_sink);
+  run<14, 0, 0>("1 wave/SIMD: tile on 32x32x16 (14 mfma)", 1, N, d_ticks, d_sink);
+  run<13, 13, 0>("2 waves/SIMD: block A on 32x32x16 x 2", 2, N, d_ticks, d_sink);
+  run<14, 14, 0>("2 waves/SIMD: tile on 32x32x16 x 2", 2, N, d_ticks, d_sink);
+  run<14, 14, 14>("3 waves/SIMD: tile on 32x32x16 x 3", 3, N, d_ticks, d_sink);
+  run<12, 5, 0>("2 waves/SIMD: mfma 32x32x16 + 32 exp", 2, N, d_ticks, d_sink);
+  run<12, 2, 0>("2 waves/SIMD: mfma 32x32x16 + (32 exp, 16 cvt, 32 fma)", 2, N, d_ticks, d_sink);
   run<8, 0, 0>("1 wave/SIMD: 16 polynomial exp2 pairs (plain VALU)", 1, N, d_ticks, d_sink);
   run<9, 0, 0>("1 wave/SIMD: block A, polynomial exp2", 1, N, d_ticks, d_sink);
   run<11, 0, 0>("1 wave/SIMD: block A, half v_exp half polynomial", 1, N, d_ticks, d_sink);

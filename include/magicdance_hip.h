@@ -180,6 +180,9 @@ typedef struct {
   int32_t kv_fp8;          /* ABI v2.  1: k0 / vt0 / k1 / vt1 hold OCP e4m3 bytes (written by md_igemm k8 / vt_fp8; leading dimensions and
                             * batch strides in bytes, multiples of 16); q stays fp16 and is converted in registers, P is converted to
                             * e4m3, both contractions run on the fp8 MFMA with fp32 accumulation (BASELINE configs[4]). */
+  int32_t causal;          /* ABI v7.  1: query i attends to keys j <= i of segment 0 (self attention of the CLIP text tower,
+                            * ldm/modules/encoders/modules.py:88-131 -> transformers' causal mask); needs nq == n0, no second segment,
+                            * fp16 K / V^T */
 } md_attention_params;
 
 int md_attention(const md_attention_params* p, void* stream);

@@ -42,7 +42,7 @@ class AttentionParams(C.Structure):
         ("n1_batches", C.c_int32),
         ("out", C.c_void_p), ("out_batch_stride", C.c_int64), ("ld_out", C.c_int32),
         ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("d", C.c_int32), ("scale", C.c_float),
-        ("q_prescaled", C.c_int32), ("kv_fp8", C.c_int32),
+        ("q_prescaled", C.c_int32), ("kv_fp8", C.c_int32), ("causal", C.c_int32),
     ]
 
 

@@ -6,9 +6,10 @@ Mirrors (same names, ctor kwargs, call signatures, cond-dict keys, state-dict ke
                                        :356-359 (q_sample), :1935 (get_first_stage_encoding), :2402-2413 (sample_log)
   DiffusionWrapper                     ddpm.py:1313-1352 (only the 'crossattn' route the pose config uses)
   create_model / instantiate_from_config   cldm/model.py:24-28, ldm/util.py:72-87
-The YAML (configs/cldm_v15_reference_only_pose.yaml) differs from the reference's only in the four ``target:`` strings.
-The first stage (VAE) is this package's own ``autoencoder.AutoencoderKL`` on the same kernels; the text encoder
- is the ``clip.FrozenCLIPEmbedder`` wrapper around stock transformers -- both named by the YAML's ``target:`` strings.
+The YAML (configs/cldm_v15_reference_only_pose.yaml) differs from the reference's only in six ``target:`` strings (model, three
+networks, first stage, text encoder).  The first stage (VAE) is this package's own ``autoencoder.AutoencoderKL`` on the
+same kernels; the text encoder is ``clip.FrozenCLIPEmbedder``: the transformers module as parameter container and
+tokenizer, its arithmetic on the GPU through ``clip.ClipTextEngine`` (this library's kernels).
 """
 import importlib
 import os

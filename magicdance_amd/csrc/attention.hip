@@ -45,6 +45,7 @@ struct AttnArgs {
   float c;  // scale * log2(e)
   int q_prescaled;  // q already carries scale * log2(e) (projection GEMM epilogue): scores come out in the exp2 domain
   int kv_fp8;       // K / V^T (both segments) are e4m3 bytes
+  int causal;       // query i attends to keys j <= i of segment 0 (attn_kernel_v2 only)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -204,6 +205,16 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
           const bool dead = kv0 + 32 * (kf >> 1) + 8 * lg + 4 * (kf & 1) + r >= nseg;
 #pragma unroll
           for (int f = 0; f < QF; ++f) st[f][kf][r] = dead ? -INFINITY : st[f][kf][r];
+        }
+    }
+    if (g.causal) {   // (uniform) keys after the query: key 0 is live for every query, so the running max is finite from tile 0 on
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kvi = kv0 + 32 * (kf >> 1) + 8 * lg + 4 * (kf & 1) + r;
+#pragma unroll
+          for (int f = 0; f < QF; ++f) st[f][kf][r] = (kvi > qbase + f * 16 + lr) ? -INFINITY : st[f][kf][r];
         }
     }
     h8 pf[QF][2];
@@ -1199,6 +1210,8 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   g.nq = p->nq;
   g.q_prescaled = p->q_prescaled ? 1 : 0;
   g.kv_fp8 = p->kv_fp8 ? 1 : 0;
+  g.causal = p->causal ? 1 : 0;
+  if (g.causal && (p->kv_fp8 || p->k1 || p->nq != p->n0)) return MD_ERR_BAD_ARG;
   g.c = g.q_prescaled ? 1.0f : p->scale * 1.4426950408889634f;   // prescaled q: the scores already are log2-domain logits
   hipStream_t s = (hipStream_t)stream;
   const double nkv = (double)p->n0 + (double)g.n1 * ((double)(g.n1_batches < p->batch ? g.n1_batches : p->batch) / p->batch);
@@ -1234,7 +1247,7 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   // v3 where it measured faster than v2 (profiles/round2_attention_microbench.txt): d = 40 (self / bank attention at 64^2,
   // 1.17-1.27x), d = 80 with 64-row query blocks (1.3x); the 77-key cross attention, d = 80 with 128-row blocks (252 VGPRs) and
   // d = 160 stay on v2.  Test geometries (d = 32 / 64 / 128) run v3.
-  const bool v3_pick = !is_cross && (p->d == 40 || (p->d == 80 && qf == 1) || p->d == 32 || p->d == 64 || p->d == 128);
+  const bool v3_pick = !is_cross && !g.causal && (p->d == 40 || (p->d == 80 && qf == 1) || p->d == 32 || p->d == 64 || p->d == 128);
   if (v3_pick) {
     switch (p->d) {
       case 40: return qf == 1 ? launch_v3<40, 1, 1>(g, s) : launch_v3<40, 2, 1>(g, s);

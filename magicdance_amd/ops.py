@@ -101,7 +101,8 @@ def ring_lds_bytes(cfg, ksize, win):
 
 
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False,
+              causal=False):
     lib = _lib.load()
     p = AttentionParams()
     p.q, p.q_batch_stride, p.ld_q = _p(q), q_bs, ld_q
@@ -115,6 +116,7 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
     p.scale = float(d) ** -0.5 if scale is None else scale
     p.q_prescaled = int(q_prescaled)
     p.kv_fp8 = int(kv_fp8)
+    p.causal = int(causal)
     _lib.check(lib.md_attention(C.byref(p), stream_ptr()), "md_attention")
     if RECORD is not None:
         nb1 = min(n1_batches, batch) if k1 is not None else 0

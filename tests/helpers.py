@@ -81,7 +81,7 @@ def head_slice(t, n=4):
     return (t[:, :n] if t.dim() == 3 else t[:, :, :1, :n]).contiguous().cpu().numpy()
 
 
-TINY_CLIP = dict(num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)   # ViT-L/14 text geometry, 2 thin layers
+TINY_CLIP = dict(num_hidden_layers=2, num_attention_heads=12, intermediate_size=64)   # ViT-L/14 text geometry (12 heads of 64), 2 thin layers
 
 
 def build_hip_model(model_channels=320, num_heads=8, seed=0, device="cuda", image_size=64, stage1=False, tiny_clip=False):

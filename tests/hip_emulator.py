@@ -133,7 +133,9 @@ def _from_e4m3(t):
 
 
 def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, ld_out, q_bs, k0_bs, vt0_bs, out_bs,
-              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False):
+              k1=None, vt1=None, n1=0, ld_k1=0, ld_vt1=0, k1_bs=0, vt1_bs=0, n1_batches=0, scale=None, q_prescaled=False, kv_fp8=False,
+              causal=False):
+    assert not causal or (nq == n0 and k1 is None and not kv_fp8)
     scale = d ** -0.5 if scale is None else scale
     if q_prescaled:   # q carries scale * log2(e): q.k is the log2-domain logit
         scale = math.log(2.0)
@@ -163,6 +165,8 @@ def attention(q, k0, vt0, out, *, batch, heads, nq, d, n0, ld_q, ld_k0, ld_vt0, 
             v1b = _mem(vt1, (n1_batches, heads, n1, d), (vt1_bs, d * ld_vt1, 1, ld_vt1)).float()[b]
             kb, vb = torch.cat([kb, k1b], 1), torch.cat([vb, v1b], 1)
         s = torch.einsum("hid,hjd->hij", qq[b], kb) * scale
+        if causal:
+            s = s.masked_fill(torch.ones(nq, n0, dtype=torch.bool).triu(1), float("-inf"))
         o[b].copy_(torch.einsum("hij,hjd->hid", s.softmax(-1), vb))
     return out
 

@@ -95,3 +95,35 @@ def test_random_text_tower_refuses_to_encode():
     e2.allow_random_weights = False
     e2.note_loaded_keys({"model.diffusion_model.x": 0})                   # a checkpoint without text-tower keys
     assert e2.weights_from == "random"
+
+
+def _clip_ids(batch, n=77, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 49405, (batch, n), generator=g)
+    ids[:, 0] = 49406
+    ids[0, 9:] = 49407                      # a short prompt: EOS padding from position 9 on
+    return ids
+
+
+def test_text_tower_on_the_c_abi_matches_transformers(monkeypatch):
+    """Host logic of ClipTextEngine (weight packing: folded LayerNorms, fused q|k|v with biases, quick-GELU as SiLU of 1.702-scaled
+    fc1 / fc2; the launch sequence; the causal flag of md_attention) on the CPU emulator of the C ABI, against the transformers
+    module it was packed from (encoders/modules.py:118-131)."""
+    from tests import hip_emulator
+    hip_emulator.install(monkeypatch)
+    cfg = dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2, projection_dim=128)
+    torch.manual_seed(0)
+    e = clip.FrozenCLIPEmbedder(device="cpu", text_config=cfg)
+    for p in e.transformer.parameters():      # biases / LayerNorm parameters away from their 0 / 1 defaults
+        p.data.add_(0.05 * torch.randn_like(p))
+    eng = clip.ClipTextEngine(e.transformer, torch.device("cpu"))
+    ids = _clip_ids(2)
+    got = eng(ids)
+    want = e.transformer(input_ids=ids).last_hidden_state
+    err = float((got - want).abs().max() / want.abs().max())
+    assert got.shape == (2, 77, 128) and err <= 4e-3, err       # fp16 storage points of the emulated launches
+    # causality: changing a later token must not change earlier positions
+    ids2 = ids.clone()
+    ids2[:, 40] = 123
+    got2 = eng(ids2)
+    assert torch.equal(got2[:, :40], got[:, :40]) and not torch.equal(got2[:, 40:], got[:, 40:])

@@ -532,6 +532,34 @@ def test_igemm_fp8_outputs(dev):
     assert torch.equal(k8, _e4m3(rk).view(torch.uint8)) or float(((kd - _e4m3(rk).float()).abs() > 0).float().mean()) < 0.02   # ties / fp32 order
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 77, 64), (1, 2, 200, 64), (1, 8, 130, 40), (2, 2, 64, 128)], ids=["clip77", "n200", "d40", "d128"])
+def test_attention_causal(dev, shape):
+    """md_attention causal (ABI v7; the CLIP text tower's self attention): query i sees keys j <= i, across tile boundaries."""
+    from magicdance_amd import ops
+    b, heads, n, d = shape
+    c = heads * d
+    q = _rand((b, n, c), 1, dev).to(F16)
+    k = _rand((b, n, c), 2, dev).to(F16)
+    v = _rand((b, n, c), 3, dev).to(F16)
+    ld = (n + 7) // 8 * 8
+    vt = torch.zeros((b, c, ld), dtype=F16, device=dev)
+    vt[:, :, :n] = v.transpose(1, 2)
+    out = torch.empty((b, n, c), dtype=F16, device=dev)
+    ops.attention(q, k, vt, out, batch=b, heads=heads, nq=n, d=d, n0=n, ld_q=c, ld_k0=c, ld_vt0=ld, ld_out=c,
+                  q_bs=n * c, k0_bs=n * c, vt0_bs=c * ld, out_bs=n * c, causal=True)
+    sp = lambda t: t.float().reshape(b, n, heads, d).permute(0, 2, 1, 3)  # noqa: E731
+    s = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
+    s = s.masked_fill(torch.ones(n, n, dtype=torch.bool, device=dev).triu(1), float("-inf"))
+    ref = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, n, c)
+    assert _err(out, ref) <= 4e-3
+    # the flag is refused where it has no meaning
+    import ctypes
+    from magicdance_amd import _lib
+    with pytest.raises(Exception):
+        ops.attention(q, k[:, :n - 1], vt, out, batch=b, heads=heads, nq=n, d=d, n0=n - 1, ld_q=c, ld_k0=c, ld_vt0=ld, ld_out=c,
+                      q_bs=n * c, k0_bs=n * c, vt0_bs=c * ld, out_bs=n * c, causal=True)
+
+
 def test_attention_spike_rescale(dev):
     """online-softmax rescale path: one key dominates from a late tile on (running max jumps)."""
     from magicdance_amd import ops

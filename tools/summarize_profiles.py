@@ -21,7 +21,7 @@ ks = os.path.join(src, "kt_kernel_stats.csv")
 if os.path.exists(ks):
     rows = list(csv.DictReader(open(ks)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    ig = [r for r in rows if "igemm_kernel" in r["Name"]]
+    ig = [r for r in rows if "igemm_kernel" in r["Name"] or "igemm_ring_kernel" in r["Name"]]
     ig_calls = sum(int(r["Calls"]) for r in ig)
     execs = sum(int(r["Calls"]) for r in rows if "ddim_update" in r["Name"])
     frames = execs / DDIM_STEPS
@@ -31,7 +31,7 @@ if os.path.exists(ks):
              f"{tot / 1e6 / execs:.2f} ms per DDIM step incl. the per-frame table pass and decode (profiled run, kernels serialised by the tracer)",
              "# columns: total_ms, ms_per_ddim_step, calls, avg_us, percent, kernel"]
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-    for r in rows[:40]:
+    for r in rows:   # every kernel: family sums must be reproducible from this file
         t = float(r["TotalDurationNs"])
         lines.append(f"{t / 1e6:10.2f} {t / 1e6 / execs:8.3f} {int(r['Calls']):8d} {float(r['AverageNs']) / 1e3:9.2f} "
                      f"{float(r['Percentage']):6.2f}  {short(r['Name'])}")
@@ -50,7 +50,7 @@ for tag, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         a = agg[short(r["Kernel_Name"])]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-    ig = {k: v for k, v in agg.items() if k.startswith("igemm_kernel")}
+    ig = {k: v for k, v in agg.items() if k.startswith("igemm_kernel") or "igemm_ring_kernel" in k}
     n = sum(v[0] for v in ig.values())
     kb = sum(v[1] for v in ig.values()) + sum(v[1] for k, v in agg.items() if k.startswith("igemm_splitk_reduce"))
     out[f"igemm_{key}_KB_per_launch_raw"] = kb / max(n, 1)

@@ -172,7 +172,9 @@ typedef struct {
   int32_t n1;
   int32_t n1_batches;      /* samples b < n1_batches attend to segment 1; the rest only to segment 0 */
   void* out; int64_t out_batch_stride; int32_t ld_out;       /* fp16 [B][Nq][ld_out] */
-  int32_t batch, heads, nq, d;  /* d in 40 / 80 / 160 (SD-1.5) or 8,16,32,64,128 (test geometries) */
+  int32_t batch, heads, nq, d;  /* d in 40 / 80 / 160 (SD-1.5) or 32 / 64 / 128 (test geometries, the CLIP text tower); any other
+                                 * head size returns MD_ERR_UNSUPPORTED, as does a K / V^T operand of 2 GiB or more (the LDS-DMA
+                                 * kernels address each operand with 32-bit byte offsets) */
   float scale;             /* d^-0.5 */
   int32_t q_prescaled;     /* ABI v2.  1: q already carries scale * log2(e) -- written that way by the projection GEMM (md_igemm
                             * col_scale), i.e. folded in before the fp16 rounding of q -- so q.k is the logit in the exp2 domain and

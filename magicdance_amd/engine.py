@@ -120,21 +120,25 @@ def _h(t, device):
     return t.detach().to(device=device, dtype=F16).contiguous()
 
 
+class TiledWeight(torch.Tensor):
+    """fp16 weight bytes in md_igemm's tiled storage.  The layout travels with the TYPE: row slices (``w[c:3 * c]``), ``.to()`` and
+    ``.clone()`` of a TiledWeight are TiledWeights (torch keeps the subclass through its ops), so a launch can never pass tiled bytes
+    with ``w_tiled = 0`` because a Python attribute got lost on the way."""
+
+
 def tile_w(w, ksize=1):
     """Packed fp16 weights [N][K] -> md_igemm's tiled storage (2 KiB blocks of 16 rows x one k-tile, k-tiles of a 16-row panel in
     consumption order; ops.tile_weights) where the buffer-loader tiles apply (N % 16 == 0, 64 | channels per tap); the returned
-    tensor carries ``_md_tiled`` = True and every launch that reads it (or a row slice of it) passes w_tiled."""
+    tensor is a ``TiledWeight`` and every launch that reads it (or a row slice of it) passes w_tiled."""
     n, k = w.shape
     cin = k // (ksize * ksize)
     if n % 16 or cin % 64:
         return w
-    t = ops.tile_weights(w, ksize)
-    t._md_tiled = True
-    return t
+    return ops.tile_weights(w, ksize).as_subclass(TiledWeight)
 
 
 def is_tiled(w):
-    return bool(getattr(w, "_md_tiled", False))
+    return isinstance(w, TiledWeight)
 
 
 def _hw(t, device):

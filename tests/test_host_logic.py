@@ -443,3 +443,16 @@ def test_tiled_weight_storage_round_trip_and_layout():
         ops.tile_weights(torch.zeros(24, 64).half())
     with pytest.raises(ValueError):
         ops.tile_weights(torch.zeros(32, 96).half())
+
+
+def test_tiled_weight_layout_travels_with_slices_and_copies():
+    """the tiled-storage flag of a packed weight must survive row slices, .to() and .clone() (a launch that passed
+    tiled bytes with w_tiled = 0 would compute silent garbage) -- it is a tensor subclass, not a Python attribute."""
+    from magicdance_amd import engine
+    w = torch.randn(96, 128).half()
+    t = engine.tile_w(w)
+    assert engine.is_tiled(t) and not engine.is_tiled(w)
+    assert engine.is_tiled(t[32:]) and engine.is_tiled(t.clone()) and engine.is_tiled(t.to(torch.float16)) and engine.is_tiled(t.view(-1))
+    assert not engine.is_tiled(engine.tile_w(torch.randn(24, 128).half()))      # N % 16 != 0: stays row-major
+    from magicdance_amd.ops import untile_weights
+    assert torch.equal(untile_weights(t, 1), w)

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
 // Round 4 (steady loop below; profiles/round4_attention_loop_ab.txt, round4_attention_pmc_d40.txt, round4_pipe_bench.txt): the
 // loop's scalar / bookkeeping work is gone -- load streams with their own descriptor + offset state, DMA issue behind the first
 // MFMAs of a tile, two tiles per trip with the score arrays swapping roles, -m as the C operand of the first k-step, the row max
-// exchanged across lane groups by v_permlane16/32_swap under the last PV MFMAs: 82 VALU + 35 SALU per tile instead of 123 + 60,
+// exchanged across lane groups by v_permlane16/32_swap under the last PV MFMAs: ~85 VALU + 40 SALU per tile instead of 123 + 60,
 // 44.9 % -> 51.8 % MFMA busy at 16 samples (d = 40), 693 -> 761 TFLOP/s; one-frame shape 549 -> 654.  What remains is the floor of
 // this instruction mix on one SIMD: v_exp_f32 (9 cycles each, 32 per wave and tile) does not overlap with MFMAs of the same SIMD,
 // within a wave or across waves (pipe_bench: 28 MFMA + 32 exp + plain VALU = 431 ns per wave-tile whatever the occupancy = 59 %

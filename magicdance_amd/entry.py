@@ -221,6 +221,13 @@ def run(args, need_dataset=False):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(args.seed)
+    if not args.use_fp16 and rank == 0:
+        # test_any_image_pose.py:237,533 -- without the flag the reference samples in fp32.  This build has ONE arithmetic (fp16 MFMA
+        # operands, fp32 accumulation, two-term residual stream): say so instead of silently ignoring the request.
+        import warnings
+        warnings.warn("--use_fp16 is absent: the reference would sample in fp32; this build always computes with fp16 matrix-core "
+                      "operands and fp32 accumulation (deviation from the reference's fp32 arithmetic: 0.6-0.9x of what the reference's "
+                      "own --use_fp16 mode shows, see DESIGN.md section 2) -- no fp32-class mode exists", stacklevel=2)
     model = _build_model(args, dev)
     h = args.image_size
     have_vae = model.first_stage_model is not None and not isinstance(model.first_stage_model, _Unavailable)

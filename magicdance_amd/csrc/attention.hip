@@ -14,6 +14,7 @@
 // The concat [self ; bank] of the reference (attention.py:305-311) is never materialised: tiles walk segment 0 then 1.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "md_common.h"
 
@@ -328,20 +329,32 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const AttnArgs g) {
 // Softmax denominator: where D is not a multiple of 16 (d = 40) the last 16-row fragment of O^T has free rows; row D of the V^T
 // tile in LDS is preset to ones (its DMA is skipped), so O^T[D][q] accumulates sum_kv P -- the row sum comes out of the PV MFMAs
 // (summing exactly the fp16 P that the numerator uses) and the per-score v_add disappears; otherwise the sum stays on the VALU.
-template <int D, int QF, int P>
+// F8 (round 4; BASELINE configs[4], the "fp8 MFMA attention path"): K and V^T are OCP e4m3 bytes in memory (md_igemm k8 / vt_fp8), Q
+// and P are converted in registers, both contractions run on v_mfma_f32_16x16x32_fp8_fp8 -- the same loop with attn_kernel_fp8's tile
+// images (K rows of 64 / 128 bytes, V^T rows of 64 bytes, 8-byte fragments, chunk XOR swizzles).  P only has 3 mantissa bits to fill,
+// so the exponentials of the steady loop leave the transcendental unit: exp2(s) ~ the float whose BITS are s * 2^23 + B (piecewise
+// linear in the fraction of s, mean-centred: relative error -3.9 % .. +2.0 %, below e4m3's own rounding step) = one v_fma + one
+// v_cvt_u32 per score instead of a 9-cycle v_exp_f32 that serialises with the MFMAs (tools/pipe_bench.hip).  The softmax denominator
+// is summed on the VALU from the same approximated P (a preset ones row would share a 16-row DMA instruction with live V^T rows).
+template <int D, int QF, int P, bool F8 = false>
 __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel_v3(const AttnArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DK = (D + 31) / 32 * 32;
   constexpr int KSTEPS = DK / 32;
   constexpr int DF = (D + 15) / 16;
-  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
+  constexpr int EB = F8 ? 1 : 2;                                  // bytes per K / V^T element
+  constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);       // fp16: 16-byte chunks per K row in LDS
   constexpr int KM = CL == 8 ? 1 : 2;
-  constexpr int KJ = 64 * CL / 256;
-  constexpr int VJ = (DF * 16 * 8 + 255) / 256;
-  constexpr int KBYTES = 64 * CL * 16, VBYTES = VJ * 4096;
+  constexpr int KC = (DK + 63) / 64 * 4;                          // fp8: 16-byte chunks per K row (rows of 64 / 128 / 192 bytes)
+  constexpr int KROWB = KC * 16;
+  constexpr int KJ = F8 ? (64 * KC + 255) / 256 : 64 * CL / 256;
+  constexpr int VJ = F8 ? (DF * 16 * 4 + 255) / 256 : (DF * 16 * 8 + 255) / 256;
+  constexpr int RPI = F8 ? 16 : 8;                                // V^T rows per DMA instruction (1 KiB)
+  constexpr int KBYTES = F8 ? KJ * 4096 : 64 * CL * 16, VBYTES = VJ * 4096;
   constexpr int BQ = 64 * QF;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr bool ONES = (D % 16) != 0;
+  constexpr bool ONES = !F8 && (D % 16) != 0;
+  typedef typename std::conditional<F8, long, h8>::type frag_t;   // one MFMA operand of a lane: 8 e4m3 bytes / 8 halves
   constexpr int LI = D / 16, LG = (D % 16) / 4, LR = D % 4;   // O^T fragment / lane group / register of row D
   constexpr int R = P + 1;                                    // ring slots: loads run P tiles ahead of the MFMAs
 
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
   const int b = hb % g.batch, h = hb / g.batch;
   const int qbase = qb * BQ + wave * (16 * QF);
 
-  h8 qf[QF][KSTEPS];
+  frag_t qf[QF][KSTEPS];
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     const int row = qbase + f * 16 + lr;
@@ -372,41 +385,71 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       const int d = ks * 32 + lg * 8;
       if (row < g.nq && d < D) v = *reinterpret_cast<const h8*>(g.q + b * g.q_bs + (long long)row * g.ld_q + h * D + d);
-      if (!g.q_prescaled) {   // generic callers: fold scale * log2(e) into Q here (the engine's projection GEMM does it in its
-#pragma unroll              // epilogue, before the fp16 rounding): the MFMAs then produce the scores in the exp2 domain
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * g.c);
+      if constexpr (F8) {
+        const float sc = g.q_prescaled ? 1.0f : g.c;
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[0] * sc, (float)v[1] * sc, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[2] * sc, (float)v[3] * sc, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[4] * sc, (float)v[5] * sc, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[6] * sc, (float)v[7] * sc, hi, true);
+        qf[f][ks] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+      } else {
+        if (!g.q_prescaled) {   // generic callers: fold scale * log2(e) into Q here (the engine's projection GEMM does it in its
+#pragma unroll                // epilogue, before the fp16 rounding): the MFMAs then produce the scores in the exp2 domain
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * g.c);
+        }
+        qf[f][ks] = v;
       }
-      qf[f][ks] = v;
     }
   }
 
   const int t1 = (g.k1 != nullptr && b < g.n1_batches) ? ((g.n1 + 63) >> 6) : 0;
   // (ceil(n0 / 64) + t1 tiles in all: the full ones run in the pipelined loop, a partial last tile of either segment in the tail below)
 
-  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.k0 + b * g.k0_bs), 0, g.n0 * g.ld_k0 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.vt0 + b * g.vt0_bs), 0, g.heads * D * g.ld_vt0 * 2, 0x00020000);
-  const half_t* k1p = g.k1 ? g.k1 + b * g.k1_bs : g.k0;
-  const half_t* v1p = g.vt1 ? g.vt1 + b * g.vt1_bs : g.vt0;
-  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(k1p), 0, (g.k1 ? g.n1 * g.ld_k1 : 0) * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(v1p), 0, (g.vt1 ? g.heads * D * g.ld_vt1 : 0) * 2, 0x00020000);
+  // (leading dimensions / batch strides are in ELEMENTS: halves, or e4m3 bytes)
+  typedef const unsigned char u8c;
+  u8c* const k0b = reinterpret_cast<u8c*>(g.k0) + b * g.k0_bs * EB;
+  u8c* const v0b = reinterpret_cast<u8c*>(g.vt0) + b * g.vt0_bs * EB;
+  u8c* const k1b = g.k1 ? reinterpret_cast<u8c*>(g.k1) + b * g.k1_bs * EB : k0b;
+  u8c* const v1b = g.vt1 ? reinterpret_cast<u8c*>(g.vt1) + b * g.vt1_bs * EB : v0b;
+  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(k0b), 0, g.n0 * g.ld_k0 * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(v0b), 0, g.heads * D * g.ld_vt0 * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(k1b), 0, (g.k1 ? g.n1 * g.ld_k1 : 0) * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(v1b), 0, (g.vt1 ? g.heads * D * g.ld_vt1 : 0) * EB, 0x00020000);
   unsigned ko0[KJ], ko1[KJ], vo0[VJ], vo1[VJ];
   int krow_[KJ], vkv_[VJ];
   // per-lane source offsets of this thread's DMA slots (functions of the thread id only): the round-4 loop keeps just the current
   // segment's set alive and recomputes the rest behind an opaque copy of the thread id (12 registers less across the loop)
   auto k_lane = [&](int tid_, int j, int ld, int& row) {
     const int i = j * 256 + tid_;
-    const int r = i / CL, pos = i % CL;
-    const int gr = 4 * ((r >> 3) & 3) + (r & 3);
-    const int sc = (pos - KM * gr) & (CL - 1);
-    row = r;
-    return (sc * 8 < D) ? (unsigned)(r * ld + h * D + sc * 8) * 2u : OOB;
+    if constexpr (F8) {   // K rows of KROWB bytes; chunk c of row r sits at position c ^ ((r >> 3) & 3) (attn_kernel_fp8's image)
+      const int r = i / KC, pos = i % KC;
+      const int sc = pos ^ ((r >> 3) & 3);
+      row = r;
+      // a chunk is fetched whole (16 bytes): the last one of a head may run into the next head's bytes -- multiplied by Q's zero
+      // padding -- or past the end of the tensor (hardware returns zeros)
+      return (i < 64 * KC && sc * 16 < D) ? (unsigned)(r * ld + h * D + sc * 16) : OOB;
+    } else {
+      const int r = i / CL, pos = i % CL;
+      const int gr = 4 * ((r >> 3) & 3) + (r & 3);
+      const int sc = (pos - KM * gr) & (CL - 1);
+      row = r;
+      return (sc * 8 < D) ? (unsigned)(r * ld + h * D + sc * 8) * 2u : OOB;
+    }
   };
   auto v_lane = [&](int tid_, int j, int ld, int& kv) {
     const int i = j * 256 + tid_;
-    const int r = i >> 3, pos = i & 7;
-    const int sc = (pos - r) & 7;
-    kv = sc * 8;
-    return (r < D) ? (unsigned)((h * D + r) * ld + sc * 8) * 2u : OOB;
+    if constexpr (F8) {   // V^T rows of 64 bytes (64 kv); chunk c of row r at position c ^ ((r >> 2) & 3)
+      const int r = i >> 2, pos = i & 3;
+      const int sc = pos ^ ((r >> 2) & 3);
+      kv = sc * 16;
+      return (r < D) ? (unsigned)((h * D + r) * ld + sc * 16) : OOB;
+    } else {
+      const int r = i >> 3, pos = i & 7;
+      const int sc = (pos - r) & 7;
+      kv = sc * 8;
+      return (r < D) ? (unsigned)((h * D + r) * ld + sc * 8) * 2u : OOB;
+    }
   };
   auto lane_offsets = [&](int tid_) {
 #pragma unroll
@@ -430,13 +473,13 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
     char* Ks = Kring + slot * KBYTES;
     const int nseg = live ? (s1 ? g.n1 : g.n0) : 0;
     if (s1) {
-      const unsigned ksoff = (unsigned)(kv0 * g.ld_k1) * 2u;
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k1) * (unsigned)EB;
 #pragma unroll
       for (int j = 0; j < KJ; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rk1, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
                                                  (kv0 + krow_[j] < nseg) ? ko1[j] : OOB, live ? ksoff : 0u, 0, 0);
     } else {
-      const unsigned ksoff = (unsigned)(kv0 * g.ld_k0) * 2u;
+      const unsigned ksoff = (unsigned)(kv0 * g.ld_k0) * (unsigned)EB;
 #pragma unroll
       for (int j = 0; j < KJ; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rk0, (__attribute__((address_space(3))) void*)(Ks + (j * 4 + wave) * 1024), 16,
@@ -446,10 +489,10 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
   auto issue_v = [&](bool live, bool s1, int kv0, int slot) {
     char* Vs = Vring + slot * VBYTES;
     const int nseg = live ? (s1 ? g.n1 : g.n0) : 0;
-    const unsigned vsoff = live ? (unsigned)kv0 * 2u : 0u;
+    const unsigned vsoff = live ? (unsigned)kv0 * (unsigned)EB : 0u;
 #pragma unroll
     for (int j = 0; j < VJ; ++j) {
-      if ((j * 4 + wave) * 8 >= D) continue;   // rows D.. : preset (ones row + zeros) when ONES, never read otherwise -- and an
+      if ((j * 4 + wave) * RPI >= D) continue;   // rows D.. : preset (ones row + zeros) when ONES, never read otherwise -- and an
                                                // instruction whose lanes are ALL out of range must not sit in a counted-vmcnt queue
       if (s1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv1, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16,
@@ -485,6 +528,62 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
 #pragma unroll
   for (int f = 0; f < QF; ++f) l_run[f] = 0.f;
 
+  // operand fragments of a lane (fp16: ds_read_b128 of 8 halves; fp8: ds_read_b64 of 8 bytes) and the MFMA of the operand type
+  auto k_frag = [&](const char* Ks, int kf, int ks) -> frag_t {
+    const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);   // permuted K rows: a lane's 8 PV k-slots are 8 consecutive kv
+    if constexpr (F8) {
+      const int slot = ks * 4 + lg;   // 8-byte slot of the row
+      return *reinterpret_cast<const long*>(Ks + row * KROWB + ((((slot >> 1) ^ ((row >> 3) & 3)) << 4) | ((slot & 1) << 3)));
+    } else {
+      return *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+    }
+  };
+  auto v_frag = [&](const char* Vs, int di, int pk) -> frag_t {
+    const int row = di * 16 + lr;
+    if constexpr (F8) {
+      const int slot = pk * 4 + lg;
+      return *reinterpret_cast<const long*>(Vs + row * 64 + ((((slot >> 1) ^ ((row >> 2) & 3)) << 4) | ((slot & 1) << 3)));
+    } else {
+      return *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+    }
+  };
+  auto mma = [](frag_t a, frag_t b2, f4 c) -> f4 {
+    if constexpr (F8) return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b2, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, c, 0, 0, 0);
+  };
+  // P of 8 scores -> one MFMA operand.  fp8: two scores per v_cvt_pk_fp8_f32 into the 16-bit halves of two dwords
+  struct PFrag {
+    h8 v;
+    int lo, hi;
+  };
+  auto p_set = [](PFrag& f, int e, float p0, float p1) {   // elements e, e + 1 (e even) of the operand
+    if constexpr (F8) {
+      // (e is a compile-time constant after unrolling: the selects fold)
+      if (e == 0) f.lo = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, f.lo, false);
+      else if (e == 2) f.lo = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, f.lo, true);
+      else if (e == 4) f.hi = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, f.hi, false);
+      else f.hi = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, f.hi, true);
+    } else {
+      f.v[e] = (half_t)p0;
+      f.v[e + 1] = (half_t)p1;
+    }
+  };
+  auto p_frag = [](const PFrag& f) -> frag_t {
+    if constexpr (F8) return (long)(((unsigned long long)(unsigned)f.hi << 32) | (unsigned)f.lo);
+    else return f.v;
+  };
+  // exp2 of a score of the steady loop.  fp8: the float whose bits are s * 2^23 + B (see the kernel's header comment)
+  auto exp2s = [](float sc) -> float {
+    if constexpr (F8) {
+      const float t = __builtin_fmaf(sc, 8388608.0f, 1064870592.0f);
+      unsigned u;
+      asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(t));   // saturating: a score far below the maximum gives 0
+      return __uint_as_float(u);
+    } else {
+      return __builtin_amdgcn_exp2f(sc);
+    }
+  };
+
   // S^T of one tile: 4 key fragments x QF query fragments
   // The S^T accumulators start at -m (running max of the query column, exp2 domain) instead of 0: the MFMAs deliver S - m and
   // the per-score subtraction of the online softmax disappears.
@@ -499,13 +598,11 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
       for (int kf = 0; kf < 4; ++kf) st[f][kf] = negm[f];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
-      const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        const h8 kfrag = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+        const frag_t kfrag = k_frag(Ks, kf, ks);
 #pragma unroll
-        for (int f = 0; f < QF; ++f)
-          st[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfrag, qf[f][ks], st[f][kf], 0, 0, 0);
+        for (int f = 0; f < QF; ++f) st[f][kf] = mma(kfrag, qf[f][ks], st[f][kf]);
       }
     }
   };
@@ -541,32 +638,32 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
       mx[f] = v;
     }
   };
-  auto exp_part = [&](const f4 (&st)[QF][4], h8 (&pf)[QF][2]) {   // P(t) = exp2(S c - m) as fp16 MFMA operands
+  auto exp_part = [&](const f4 (&st)[QF][4], PFrag (&pf)[QF][2]) {   // P(t) = exp2(S c - m) as MFMA operands (exact exp2: rare paths)
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
       [[maybe_unused]] float ps = 0.f;
 #pragma unroll
+      for (int pk = 0; pk < 2; ++pk) pf[f][pk].lo = pf[f][pk].hi = 0;
+#pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[f][kf][r]);
-          if constexpr (!ONES) ps += p;
-          pf[f][kf >> 1][(kf & 1) * 4 + r] = (half_t)p;
+        for (int r = 0; r < 4; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(st[f][kf][r]), p1 = __builtin_amdgcn_exp2f(st[f][kf][r + 1]);
+          if constexpr (!ONES) ps += p0 + p1;
+          p_set(pf[f][kf >> 1], (kf & 1) * 4 + r, p0, p1);
         }
       if constexpr (!ONES) l_run[f] += ps;
     }
   };
-  auto pv = [&](int slot, const h8 (&pf)[QF][2]) {
+  auto pv = [&](int slot, const PFrag (&pf)[QF][2]) {
     const char* Vs = Vring + slot * VBYTES;
 #pragma unroll
     for (int i = 0; i < DF; ++i) {
-      const int row = i * 16 + lr;
 #pragma unroll
       for (int pk = 0; pk < 2; ++pk) {
-        const h8 vfrag = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+        const frag_t vfrag = v_frag(Vs, i, pk);
 #pragma unroll
-        for (int f = 0; f < QF; ++f)
-          o[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf[f][pk], o[i][f], 0, 0, 0);
+        for (int f = 0; f < QF; ++f) o[i][f] = mma(vfrag, p_frag(pf[f][pk]), o[i][f]);
       }
     }
   };
@@ -656,9 +753,9 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
         for (int j = 0; j < KJ; ++j) kvo[j] = k_lane(tid_l, j, ks1 ? g.ld_k1 : g.ld_k0, unused_row);
 #pragma unroll
         for (int j = 0; j < VJ; ++j) vvo[j] = v_lane(tid_l, j, vs1 ? g.ld_vt1 : g.ld_vt0, unused_row);
-        k_step = (unsigned)(64 * (ks1 ? g.ld_k1 : g.ld_k0)) * 2u;
+        k_step = (unsigned)(64 * (ks1 ? g.ld_k1 : g.ld_k0)) * (unsigned)EB;
         k_soff = (unsigned)(ks1 ? k_tile - nf0 : k_tile) * k_step;
-        v_soff = (unsigned)(vs1 ? v_tile - nf0 : v_tile) * 128u;
+        v_soff = (unsigned)(vs1 ? v_tile - nf0 : v_tile) * (64u * EB);
         k_left = (ks1 ? nfull : nf0) - k_tile;
         v_left = (vs1 ? nfull : nf0) - v_tile;
       }
@@ -675,7 +772,7 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
           kd = rk1;
 #pragma unroll
           for (int j = 0; j < KJ; ++j) kvo[j] = k_lane(tid_l, j, g.ld_k1, unused_row);
-          k_step = (unsigned)(64 * g.ld_k1) * 2u;
+          k_step = (unsigned)(64 * g.ld_k1) * (unsigned)EB;
           k_soff = 0u;
         }
       };
@@ -684,12 +781,12 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
           char* Vs = Vring + (v_tile & 1) * VBYTES;
 #pragma unroll
           for (int j = 0; j < VJ; ++j) {
-            if ((j * 4 + wave) * 8 >= D) continue;
+            if ((j * 4 + wave) * RPI >= D) continue;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vd, (__attribute__((address_space(3))) void*)(Vs + (j * 4 + wave) * 1024), 16, vvo[j], v_soff, 0, 0);
           }
         }
         ++v_tile;
-        v_soff += 128u;
+        v_soff += 64u * EB;
         if (--v_left == 0) {
           vd = rv1;
 #pragma unroll
@@ -726,38 +823,39 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1) and V(t) have landed (this wave's share); every wave is done with
         __builtin_amdgcn_s_barrier();                      // the slots of K(t) and V(t-1)
         __builtin_amdgcn_sched_barrier(0);
-        h8 pf[QF][2];
+        PFrag pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+          for (int pk = 0; pk < 2; ++pk) pf[f][pk].lo = pf[f][pk].hi = 0;
         float mx[QF];
         const char* Ks = Kring + ((t + 1) & 1) * KBYTES;
         const char* Vs = Vring + (t & 1) * VBYTES;
-        h8 kfr[4][KSTEPS];
+        frag_t kfr[4][KSTEPS];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-          const int row = 32 * (kf >> 1) + 8 * (lr >> 2) + 4 * (kf & 1) + (lr & 3);
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks)
-            kfr[kf][ks] = *reinterpret_cast<const h8*>(Ks + row * (CL * 16) + (((ks * 4 + lg + KM * lr) & (CL - 1)) << 4));
+          for (int ks = 0; ks < KSTEPS; ++ks) kfr[kf][ks] = k_frag(Ks, kf, ks);
         }
         [[maybe_unused]] float ps[QF];
 #pragma unroll
         for (int f = 0; f < QF; ++f) ps[f] = 0.f;
         __builtin_amdgcn_sched_barrier(0);
-        h8 vfr[DF][2];
+        frag_t vfr[DF][2];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           const int kf = i / (KSTEPS * QF), ks = (i / QF) % KSTEPS, f = i % QF;
           if (ks == 0)
-            sn[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], negm[f], 0, 0, 0);
+            sn[f][kf] = mma(kfr[kf][ks], qf[f][ks], negm[f]);
           else
-            sn[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[kf][ks], qf[f][ks], sn[f][kf], 0, 0, 0);
+            sn[f][kf] = mma(kfr[kf][ks], qf[f][ks], sn[f][kf]);
 #pragma unroll
           for (int pp = (i * NP) / NA; pp < ((i + 1) * NP) / NA; ++pp) {   // this step's share of the score pairs of tile t
             const int pf_ = pp / 8, pkf = (pp % 8) / 2, pr = (pp % 2) * 2;
-            const float p0 = __builtin_amdgcn_exp2f(sc[pf_][pkf][pr]);
-            const float p1 = __builtin_amdgcn_exp2f(sc[pf_][pkf][pr + 1]);
+            const float p0 = exp2s(sc[pf_][pkf][pr]);
+            const float p1 = exp2s(sc[pf_][pkf][pr + 1]);
             if constexpr (!ONES) ps[pf_] += p0 + p1;
-            pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr] = (half_t)p0;
-            pf[pf_][pkf >> 1][(pkf & 1) * 4 + pr + 1] = (half_t)p1;
+            p_set(pf[pf_][pkf >> 1], (pkf & 1) * 4 + pr, p0, p1);
           }
           if (i == 1) {   // the next tiles' loads leave behind the first MFMAs
             stream_k();
@@ -766,9 +864,8 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
           if (i == NA - 1 - VEARLY) {   // V^T fragments of tile t: requested under the last MFMAs of block A
 #pragma unroll
             for (int di = 0; di < DF; ++di) {
-              const int row = di * 16 + lr;
 #pragma unroll
-              for (int pk = 0; pk < 2; ++pk) vfr[di][pk] = *reinterpret_cast<const h8*>(Vs + row * 128 + (((4 * pk + lg + row) & 7) << 4));
+              for (int pk = 0; pk < 2; ++pk) vfr[di][pk] = v_frag(Vs, di, pk);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -785,7 +882,7 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int di = i / (2 * QF), pk = (i / QF) % 2, f = i % QF;
-          o[di][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[di][pk], pf[f][pk], o[di][f], 0, 0, 0);
+          o[di][f] = mma(vfr[di][pk], p_frag(pf[f][pk]), o[di][f]);
           {
             if (i < NB1) {
 #pragma unroll
@@ -823,7 +920,7 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
     {  // last full tile: its V was issued in the previous iteration (or in the prologue)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      h8 pf[QF][2];
+      PFrag pf[QF][2];
       exp_part(st, pf);
       pv(slot_of(nfull - 1), pf);
     }
@@ -857,7 +954,7 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
     } else {
       rescale_to(mx, st, 0.f);
     }
-    h8 pf[QF][2];
+    PFrag pf[QF][2];
     exp_part(st, pf);
     pv(0, pf);
   }
@@ -890,27 +987,29 @@ __global__ __launch_bounds__(256, (D == 40 && QF == 2) ? 3 : 1) void attn_kernel
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int D, int QF, int P>
+template <int D, int QF, int P, bool F8 = false>
 int launch_v3(const AttnArgs& g, hipStream_t s) {
   constexpr int DK = (D + 31) / 32 * 32;
   constexpr int DF = (D + 15) / 16;
   constexpr int CL = DK <= 64 ? 8 : (DK <= 128 ? 16 : 32);
-  constexpr int VJ = (DF * 16 * 8 + 255) / 256;
-  constexpr size_t lds = (size_t)(P + 1) * (64 * CL * 16 + VJ * 4096);
+  constexpr int KC = (DK + 63) / 64 * 4;
+  constexpr int KJ = F8 ? (64 * KC + 255) / 256 : 64 * CL / 256;
+  constexpr int VJ = F8 ? (DF * 16 * 4 + 255) / 256 : (DF * 16 * 8 + 255) / 256;
+  constexpr size_t lds = (size_t)(P + 1) * ((F8 ? KJ * 4096 : 64 * CL * 16) + VJ * 4096);
   static_assert(lds <= 160 * 1024, "ring does not fit the 160 KB LDS");
   static bool attr_set[64] = {};
   if (lds > 65536) {
     int devi = 0;
     MD_HIP_CHECK(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v3<D, QF, P>),
+      MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_v3<D, QF, P, F8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (devi >= 0 && devi < 64) attr_set[devi] = true;
     }
   }
   constexpr int BQ = 64 * QF;
   dim3 grid(((g.nq + BQ - 1) / BQ) * g.heads * g.batch);
-  hipLaunchKernelGGL((attn_kernel_v3<D, QF, P>), grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL((attn_kernel_v3<D, QF, P, F8>), grid, dim3(256), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
@@ -945,9 +1044,9 @@ int launch_v2(const AttnArgs& g, hipStream_t s) {
 // fp8 variant (BASELINE configs[4], "fp8 MFMA attention path"): K and V^T are OCP e4m3 in memory (written that way by the
 // projection GEMM's epilogue, md_igemm k8 / vt_fp8), Q (fp16 in memory) and P are converted to e4m3 in registers, both
 // contractions run on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation; softmax statistics stay fp32.  Half the K / V^T bytes
-// per tile (the MFMA rate of the non-scaled fp8 form equals the fp16 rate on gfx950, and the kernel is VALU-bound on its softmax:
-// this path is about operand bytes and about exercising the fp8 matrix path, not about speed).  Structure = v2's 2-stage LDS-DMA
-// loop.  Tiles: K 64 rows x DKB bytes (DKB = 64 / 128 / 192 >= d, 16-byte chunks), V^T DV rows x 64 bytes; a lane's MFMA operand
+// per tile (the MFMA rate of the non-scaled fp8 form equals the fp16 rate on gfx950).  This is the plain form -- v2's 2-stage LDS-DMA
+// loop, exact exponentials -- that serves the 77-key cross attention, d = 160 and the test head sizes; self / bank attention at
+// d = 40 / 80 runs attn_kernel_v3<D, QF, 1, true> (round 4), which is also where the fp8 path gets faster than the fp16 one.  Tiles: K 64 rows x DKB bytes (DKB = 64 / 128 / 192 >= d, 16-byte chunks), V^T DV rows x 64 bytes; a lane's MFMA operand
 // is 8 consecutive bytes (ds_read_b64).  Swizzles (on 16-byte chunks, applied to the DMA source): K chunk ^ ((row >> 3) & 3),
 // V^T chunk ^ ((row >> 2) & 3): the 32 lanes of one ds_read_b64 pass then cover 32 distinct 8-byte slots of the 256-byte bank
 // window.  K rows are permuted as in v2 so that the 8 kv a lane feeds to the PV MFMA are 8 consecutive bytes of a V^T row.
@@ -1226,6 +1325,13 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
     // e4m3 K / V^T: byte tensors, 16-byte aligned rows (the DMA moves 16-byte chunks)
     if ((p->ld_k0 & 15) || (p->ld_vt0 & 15) || (p->k1 && ((p->ld_k1 & 15) || (p->ld_vt1 & 15)))) return MD_ERR_BAD_ARG;
     if ((p->k0_batch_stride & 15) || (p->vt0_batch_stride & 15) || (p->k1_batch_stride & 15) || (p->vt1_batch_stride & 15)) return MD_ERR_BAD_ARG;
+    // self / bank attention at d = 40 / 80: the pipelined loop on fp8 operands (round 4); everything else (77-key cross attention,
+    // d = 160, the power-of-two test head sizes) stays on the plain 2-stage kernel
+    if (p->n0 == p->nq && !getenv("MD_FP8_V2")) {
+      const long long wg128f = (long long)((p->nq + 127) / 128) * p->heads * p->batch;
+      if (p->d == 40) return wg128f >= 512 ? launch_v3<40, 2, 1, true>(g, s) : launch_v3<40, 1, 1, true>(g, s);
+      if (p->d == 80) return launch_v3<80, 1, 1, true>(g, s);
+    }
     switch (p->d) {
       case 40: return launch_fp8<40>(g, s);
       case 80: return launch_fp8<80>(g, s);

@@ -470,8 +470,11 @@ def _e4m3(t):
 def test_attention_fp8(dev, case):
     """md_attention kv_fp8 (BASELINE configs[4] path): K / V^T as OCP e4m3 bytes, q and P converted in registers, fp8 MFMA with
     fp32 accumulation.  Checked against fp32 attention over the SAME e4m3 operands (K, V, q): what remains is the e4m3 rounding
-    of P (3 mantissa bits, uniform over the keys -> averages out) -- 2e-2 abs on O(1) outputs; the unquantised fp32 attention is
-    a sanity bound only (unit-variance random q / k / v over a few hundred keys are a worst case for 3-bit mantissas: 0.12 measured)."""
+    of P (3 mantissa bits, uniform over the keys -> averages out) -- 2e-2 abs on O(1) outputs -- and, where the pipelined loop runs
+    (self / bank attention at d = 40 / 80, round 4), the piecewise-linear exp2 of its steady loop (-3.9 % .. +2.0 % per weight,
+    mean-centred, below the e4m3 rounding step; measured 2.9e-2 on this 392-key case, bound 3.5e-2; at the production shapes -- thousands
+    of keys -- the rms error moves from 8.6e-4 to 9.5e-4, profiles/round4_attention_fp8_ab.txt); the unquantised fp32 attention is a
+    sanity bound only (unit-variance random q / k / v over a few hundred keys are a worst case for 3-bit mantissas: 0.12 measured)."""
     from magicdance_amd import ops
     name, b, heads, nq, n0, n1, n1b, d = case
     c = heads * d
@@ -505,7 +508,7 @@ def test_attention_fp8(dev, case):
         ref_q[i] = torch.einsum("bhij,bhjd->bhid", s_q.softmax(-1), sp(vq)).permute(0, 2, 1, 3).reshape(nq, c)
         s_f = torch.einsum("bhid,bhjd->bhij", sp(q[i:i + 1]), sp(kk)) * d ** -0.5
         ref[i] = torch.einsum("bhij,bhjd->bhid", s_f.softmax(-1), sp(vv)).permute(0, 2, 1, 3).reshape(nq, c)
-    assert _err(out, ref_q) <= 2e-2, name
+    assert _err(out, ref_q) <= (3.5e-2 if (n0 == nq and d in (40, 80)) else 2e-2), name
     assert _err(out, ref) <= 2.5e-1, name
 
 

@@ -274,6 +274,22 @@ int md_ddim_update(const float* eps_c, const float* eps_u, int32_t ld_eps, const
                    const float* coef, float* x_prev, float* pred_x0, float* eps_out, int32_t batch, int32_t c,
                    int32_t hw, void* stream);
 
+/* ABI v8: temporal overlap sampling (DDIMSampler_ReferenceOnly.p_sample_ddim, ldm/models/diffusion/ddim.py:569-594) inside a captured
+ * step: every DDIM step visits the frame sequence in WINDOWS of n_idx = 16 frames (stride 12, starting at a random frame offset,
+ * wrapping around), applies classifier-free guidance per window, accumulates the guided predictions per frame and divides by the
+ * visit count.  The frame indices of all steps / windows sit in a device table idx_table [steps][windows][n_idx] (int32); the step is
+ * read from the device counter (clamped to the table), so the launches are replayable from a HIP graph.
+ *   md_gather_frames   dst[j] = src[idx[j]], j < n_idx: rows of row_bytes bytes (a multiple of 16) -- x_t and the pose features of a window
+ *   md_cfg_scatter_add pred[idx[j]] += e_u[j] + coef[4] (e_c[j] - e_u[j]), counts[idx[j]] += 1   (eps NHWC fp32 [n_idx][hw][ld_eps],
+ *                      pred fp32 [frames][hw][c]; ddim.py:586-590, the round trip through the CPU dropped)
+ *   md_window_mean     eps[f] = pred[f] / counts[f] for every frame (ddim.py:592-593), then clears pred / counts for the next step */
+int md_gather_frames(const void* src, void* dst, const int32_t* idx_table, const int32_t* step_counter, int32_t steps, int32_t windows,
+                     int32_t window, int32_t n_idx, int64_t row_bytes, void* stream);
+int md_cfg_scatter_add(const float* eps_c, const float* eps_u, int32_t ld_eps, const float* coef, const int32_t* idx_table,
+                       const int32_t* step_counter, int32_t steps, int32_t windows, int32_t window, int32_t n_idx, float* pred,
+                       float* counts, int32_t hw, int32_t c, void* stream);
+int md_window_mean(float* pred, float* counts, float* eps, int32_t frames, int64_t per_frame, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Runtime: HIP-graph capture of a launch sequence and per-kernel-family timing
  * ------------------------------------------------------------------------------------------------------- */

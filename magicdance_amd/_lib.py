@@ -81,6 +81,9 @@ SIGNATURES = {
     "md_gather_rows": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "md_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "md_ddim_update": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "md_gather_frames": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "md_cfg_scatter_add": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "md_window_mean": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "md_graph_begin": (C.c_int, [_vp]),
     "md_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
     "md_graph_launch": (C.c_int, [_vp, _vp]),

@@ -275,6 +275,95 @@ extern "C" int md_counter_add(int32_t* counter, int32_t delta, void* stream) {
   return MD_OK;
 }
 
+// ---- temporal overlap sampling (ddim.py:569-594) inside a captured step: windows of frames picked by a device index table ---------
+// idx_table [steps][windows][n_idx] int32; the step is the device counter (clamped to the table), the window a launch argument.
+namespace {
+__global__ __launch_bounds__(256) void gather_frames_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                            const int32_t* __restrict__ idx_table, const int32_t* __restrict__ counter,
+                                                            int steps, int windows, int window, int n_idx, long long row_vec) {
+  const int st = min(max(counter ? counter[0] : 0, 0), steps - 1);
+  const int32_t* idx = idx_table + ((long long)st * windows + window) * n_idx;
+  const long long total = (long long)n_idx * row_vec;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / row_vec);
+    dst[i] = src[(long long)idx[j] * row_vec + (i - (long long)j * row_vec)];
+  }
+}
+// pred[idx[j]][p][ch] += e_u + scale (e_c - e_u) for the window's n_idx frames (distinct inside a window; windows of a step run one
+// after the other on the stream), counts[idx[j]] += 1.  eps: NHWC fp32 [n_idx][hw][ld_eps]; pred: [frames][hw][c]
+__global__ __launch_bounds__(256) void cfg_scatter_add_kernel(const float* __restrict__ eps_c, const float* __restrict__ eps_u, int ld_eps,
+                                                              const float* __restrict__ coef, const int32_t* __restrict__ idx_table,
+                                                              const int32_t* __restrict__ counter, int steps, int windows, int window,
+                                                              int n_idx, float* __restrict__ pred, float* __restrict__ counts, int hw, int c) {
+  const int st = min(max(counter ? counter[0] : 0, 0), steps - 1);
+  const int32_t* idx = idx_table + ((long long)st * windows + window) * n_idx;
+  const float scale = coef[4];
+  const long long per = (long long)hw * c, total = (long long)n_idx * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / per);
+    const long long r = i - (long long)j * per;
+    const long long pix = r / c;
+    const int ch = (int)(r - pix * c);
+    const long long e = ((long long)j * hw + pix) * ld_eps + ch;
+    const float eu = eps_u[e];
+    pred[(long long)idx[j] * per + r] += eu + scale * (eps_c[e] - eu);
+    if (r == 0) counts[idx[j]] += 1.0f;
+  }
+}
+// eps[f] = pred[f] / counts[f] (every frame is visited by at least one window), then pred and counts are cleared for the next step
+__global__ __launch_bounds__(256) void window_mean_kernel(float* __restrict__ pred, float* __restrict__ counts, float* __restrict__ eps,
+                                                          long long per) {
+  const int f = blockIdx.x;
+  const float inv = 1.0f / counts[f];
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    eps[(long long)f * per + i] = pred[(long long)f * per + i] * inv;
+    pred[(long long)f * per + i] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[f] = 0.f;
+}
+}  // namespace
+
+extern "C" int md_gather_frames(const void* src, void* dst, const int32_t* idx_table, const int32_t* step_counter, int32_t steps,
+                                int32_t windows, int32_t window, int32_t n_idx, int64_t row_bytes, void* stream) {
+  if (!src || !dst || !idx_table || steps <= 0 || windows <= 0 || window < 0 || window >= windows || n_idx <= 0 || row_bytes <= 0 ||
+      (row_bytes & 15))
+    return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, 2.0 * n_idx * (double)row_bytes);
+  const long long total = (long long)n_idx * (row_bytes >> 4);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(gather_frames_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst,
+                     idx_table, step_counter, steps, windows, window, n_idx, (long long)(row_bytes >> 4));
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_cfg_scatter_add(const float* eps_c, const float* eps_u, int32_t ld_eps, const float* coef, const int32_t* idx_table,
+                                  const int32_t* step_counter, int32_t steps, int32_t windows, int32_t window, int32_t n_idx,
+                                  float* pred, float* counts, int32_t hw, int32_t c, void* stream) {
+  if (!eps_c || !eps_u || !coef || !idx_table || !pred || !counts || steps <= 0 || windows <= 0 || window < 0 || window >= windows ||
+      n_idx <= 0 || hw <= 0 || c <= 0 || ld_eps < c)
+    return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, 16.0 * n_idx * (double)hw * c);
+  const long long total = (long long)n_idx * hw * c;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(cfg_scatter_add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, eps_c, eps_u, ld_eps, coef,
+                     idx_table, step_counter, steps, windows, window, n_idx, pred, counts, hw, c);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
+extern "C" int md_window_mean(float* pred, float* counts, float* eps, int32_t frames, int64_t per_frame, void* stream) {
+  if (!pred || !counts || !eps || frames <= 0 || per_frame <= 0) return MD_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  md::ProfScope prof(MD_FAM_ELEMENTWISE, s, 0.0, 12.0 * frames * (double)per_frame);
+  hipLaunchKernelGGL(window_mean_kernel, dim3(frames), dim3(256), 0, s, pred, counts, eps, (long long)per_frame);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 extern "C" int md_ddim_update(const float* eps_c, const float* eps_u, int32_t ld_eps, const float* x,
                               const float* noise, const float* coef, float* x_prev, float* pred_x0, float* eps_out,
                               int32_t batch, int32_t c, int32_t hw, void* stream) {

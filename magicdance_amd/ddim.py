@@ -182,14 +182,22 @@ class DDIMSampler_ReferenceOnly(object):
     def _fused_ok(self, c, uc, scale):
         """The fused (table + captured graph) route covers eta = 0 sampling of: the entry points' default -- "controlnet is more
         important" CFG (:595-605) with ``wonoise`` --, the "balance" CFG branch (:540-567: the unconditional dict carries the
-        reference too), the noisy reference (``wonoise`` False, :529-535) and the stage-1 model without pose ControlNet.  Everything
-        else (overlap_sampling windows, eta > 0, a void text context, guidance scale 1) takes the generic per-call route."""
+        reference too), the noisy reference (``wonoise`` False, :529-535), the stage-1 model without pose ControlNet and the temporal
+        ``overlap_sampling`` windows (:569-594).  Everything else (eta > 0, a void text context, guidance scale 1, overlap windows over
+        per-frame references) takes the generic per-call route."""
         if uc is None or scale == 1. or not isinstance(c, dict) or not isinstance(uc, dict):
             return False
-        if c.get("overlap_sampling") or c.get("image_control") is None or c.get("c_crossattn_void") is not None:
+        if c.get("image_control") is None or c.get("c_crossattn_void") is not None:
             return False
         if getattr(self.model, "has_pose", True) and c.get("c_concat") is None:
             return False
+        if c.get("overlap_sampling"):
+            # temporal overlap windows (:569-594) inside the step graph (round 4): the entry points' form -- pose model, clean shared
+            # reference, shared text, at least one full window of frames; anything else keeps the per-call route
+            one = lambda ts: sum(t.shape[0] for t in ts) // max(1, len(ts)) == 1 or FusedStepRunner._same_rows(torch.cat(ts, 1))  # noqa: E731
+            if not (getattr(self.model, "has_pose", True) and c.get("wonoise", True) and uc.get("image_control") is None
+                    and c["c_concat"][0].shape[0] >= FusedStepRunner.OV_WIN and one(c["image_control"]) and one(c["c_crossattn"])):
+                return False
         if uc.get("image_control") is not None:   # balance: both halves of the 2B batch are conditional passes
             for k in c:
                 if isinstance(c[k], list) and (k not in uc or len(uc[k]) != len(c[k])):
@@ -261,6 +269,8 @@ class FusedStepRunner:
     multi-frame sequences sharing one reference image.
     """
 
+    OV_WIN, OV_STRIDE = 16, 12      # overlap_sampling: frames per window / window stride (ddim.py:577)
+
     def __init__(self, model):
         self.model = model
         self.key = None
@@ -309,10 +319,15 @@ class FusedStepRunner:
         assert table_mode, "the fused route always runs from the reference-KV table"
         model, dev = self.model, self.model.device
         app, pose_e, unet = model.engines()
-        b, cch, hh, ww = x_T.shape
+        nf, cch, hh, ww = x_T.shape
+        # overlap_sampling (ddim.py:569-594): the state x holds all nf frames, the networks run on windows of OV_WIN frames picked by a
+        # per-step index table (python ``random`` offsets drawn HERE, in step order, exactly as the per-step route draws them)
+        overlap = bool(c.get("overlap_sampling"))
+        b = self.OV_WIN if overlap else nf
         balance = uc is not None and uc.get("image_control") is not None
         noisy = not c.get("wonoise", True)
         has_pose = pose_e is not None
+        assert not overlap or (has_pose and not balance and not noisy and nf >= self.OV_WIN)
         ref = torch.cat(c["image_control"], 1).detach().to(device=dev, dtype=F32)
         ctx = torch.cat(c["c_crossattn"], 1).detach().to(device=dev, dtype=F32)
         rep = lambda t, n: t if t.shape[0] == n else t.expand(n, *t.shape[1:])  # noqa: E731
@@ -364,10 +379,10 @@ class FusedStepRunner:
             self.kv_pose = self.kv_merged = None
         self.kv_unet_uc = self.kv_unet if self._ctx_unet.shape[0] == 1 else [
             (k[:b], vt[:b], b, tk, ldv) for (k, vt, bc, tk, ldv) in self.kv_unet]  # per-sample text: first half of the 2B batch
-        key = (b, cch, hh, ww, S, bref, tuple(hint.shape), balance, noisy, self.kv_app[0][0].data_ptr(),
+        key = (b, nf, overlap, cch, hh, ww, S, bref, tuple(hint.shape), balance, noisy, self.kv_app[0][0].data_ptr(),
                0 if self.kv_pose is None else self.kv_pose[0][0].data_ptr(), self.kv_unet[0][0].data_ptr())
         if key != self.key:
-            self._allocate(key, b, cch, hh, ww, S, bref, True)
+            self._allocate(key, b, cch, hh, ww, S, bref, True, nf=nf, overlap=overlap)
         per, nblocks = self.plan_table(S, bref, world, sharded)
         from . import engine as _eng
         tkey = (cch, hh, ww, S, bref, per, nblocks, _eng.ATTN_FP8)
@@ -377,10 +392,25 @@ class FusedStepRunner:
         self.x.copy_(x_T)
         if has_pose:
             hf = pose_e.hint_features(hint)
-            if self.hint_feat is None or self.hint_feat.t.shape != hf.t.shape:
-                self.hint_feat = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
-                self._drop_graph()
-            self.hint_feat.t.copy_(hf.t)
+            if overlap:   # features of ALL frames stay resident; a window's rows are gathered into hint_feat inside the step
+                if self.hint_all is None or self.hint_all.t.shape != hf.t.shape:
+                    self.hint_all = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
+                    self.hint_feat = type(hf)(torch.empty((b,) + tuple(hf.t.shape[1:]), dtype=hf.t.dtype, device=dev), b, hf.h, hf.w, hf.c)
+                    self._drop_graph()
+                self.hint_all.t.copy_(hf.t)
+            else:
+                if self.hint_feat is None or self.hint_feat.t.shape != hf.t.shape:
+                    self.hint_feat = type(hf)(torch.empty_like(hf.t), hf.b, hf.h, hf.w, hf.c)
+                    self._drop_graph()
+                self.hint_feat.t.copy_(hf.t)
+        if overlap:
+            offs = [random.randint(0, nf - 1) for _ in range(S)]                                   # :572, one draw per step
+            starts = [list(range(o, o + nf - self.OV_WIN + 1 + self.OV_STRIDE, self.OV_STRIDE)) for o in offs]   # :577
+            tab = np.array([[[(s0 + j) % nf for j in range(self.OV_WIN)] for s0 in st] for st in starts], dtype=np.int32)
+            assert tab.shape == tuple(self.ov_idx.shape), (tab.shape, self.ov_idx.shape)
+            self.ov_idx.copy_(torch.from_numpy(tab))
+            self.ov_pred.zero_()
+            self.ov_counts.zero_()
         # per-step tables: timestep (as float, repeated for the 2B-sample UNet batch) and DDIM coefficients
         steps = np.flip(sampler.ddim_timesteps).astype(np.float32)
         idx = np.arange(S)[::-1]
@@ -418,13 +448,23 @@ class FusedStepRunner:
             self.graph.destroy()
             self.graph = None
 
-    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode):
+    def _allocate(self, key, b, cch, hh, ww, S, bref, table_mode, nf=None, overlap=False):
         dev = self.model.device
         self._drop_graph()
+        nf = b if nf is None else nf
         self.key, self.table_mode = key, table_mode
-        self.b, self.cch, self.hw, self.S = b, cch, hh * ww, S
-        self.x = torch.empty((b, cch, hh, ww), dtype=F32, device=dev)
+        self.b, self.cch, self.hw, self.S, self.nf, self.overlap = b, cch, hh * ww, S, nf, overlap
+        self.x = torch.empty((nf, cch, hh, ww), dtype=F32, device=dev)      # the DDIM state (all frames)
         self.pred_x0 = torch.empty_like(self.x)
+        self.xw = self.x                                                     # what the networks see (overlap: one window of frames)
+        self.hint_all = None
+        if overlap:
+            nwin = len(range(0, nf - self.OV_WIN + 1 + self.OV_STRIDE, self.OV_STRIDE))
+            self.xw = torch.empty((b, cch, hh, ww), dtype=F32, device=dev)
+            self.ov_idx = torch.zeros((S, nwin, self.OV_WIN), dtype=torch.int32, device=dev)
+            self.ov_pred = torch.zeros((nf, hh * ww, cch), dtype=F32, device=dev)       # guided eps accumulated per frame (NHWC)
+            self.ov_counts = torch.zeros((nf,), dtype=F32, device=dev)
+            self.ov_eps = torch.empty((nf, hh * ww, cch), dtype=F32, device=dev)
         self.ref = torch.empty((bref, cch, hh, ww), dtype=F32, device=dev)
         self.hint_feat = None
         self.ts_table = torch.empty((S, 2 * b), dtype=F32, device=dev)
@@ -592,30 +632,44 @@ class FusedStepRunner:
         arena.reset()
         main = torch.cuda.current_stream()
         oc = unet.cfg.out_channels
-        eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
-        ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
+        ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
+                        self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
+        if self.overlap:
+            # ddim.py:569-594: every window of 16 frames through the networks, guided predictions accumulated per frame, mean over the
+            # visits, ONE DDIM update of all frames.  Windows run one after the other on this stream (they may share frames).
+            for w in range(self.ov_idx.shape[1]):
+                arena.reset()
+                ops.gather_frames(self.x, self.xw, self.ov_idx, self.counter, w, self.cch * self.hw * 4)
+                ops.gather_frames(self.hint_all.t, self.hint_feat.t, self.ov_idx, self.counter, w,
+                                  self.hint_all.t[0].numel() * self.hint_all.t.element_size())
+                eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
+                ops.cfg_scatter_add(eps_c, eps_u, oc, self.coef_cur, self.ov_idx, self.counter, w, self.ov_pred, self.ov_counts,
+                                    self.hw, self.cch)
+            ops.window_mean(self.ov_pred, self.ov_counts, self.ov_eps, self.nf, self.hw * self.cch)
+            ops.ddim_update(self.ov_eps, None, self.cch, self.x, None, self.coef_cur, self.x, self.pred_x0, None, self.nf, self.cch, self.hw)
+        else:
+            eps_c, eps_u = self._networks(model, pose_e, unet, b, main)
+            ops.ddim_update(eps_c, eps_u, oc, self.x, None, self.coef_cur, self.x, self.pred_x0, None, b, self.cch, self.hw)
         ops.counter_add(self.counter, 1)
 
     def _networks(self, model, pose_e, unet, b, main):
-        """the network passes of one step: (eps_cond, eps_uncond), NHWC fp32"""
-        ops.gather_rows(self.bank_table, self.bank_seg, self.bank_seg.shape[0], self.bank_seg_max, self.counter, 0,
-                        self.bank_cur, self.S, self.per, self.block_elems // self.table_unit)
+        """the network passes of one step on ``self.xw``: (eps_cond, eps_uncond), NHWC fp32"""
         banks = self.bank_cur_kv
         nread, n_pose = self.nread, self.n_pose
         if pose_e is None:
-            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, nread=nread,
+            eps = unet.unet([self.xw, self.xw], self.t_cur, self.kv_unet, banks=banks, nread=nread,
                             only_mid_control=model.only_mid_control, emb=self.emb_cur_unet)
         elif self.merge_pose:
             # the pose ControlNet rides in the UNet encoder's launches (second parameter set): no stream of its own
-            eps = unet.unet_pose(pose_e, self.x, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
+            eps = unet.unet_pose(pose_e, self.xw, self.hint_feat, self.kv_unet, self.kv_merged, self.emb_cur_unet,
                                  self.emb_cur_pose, banks=banks, nread=nread, n_pose=n_pose, only_mid_control=model.only_mid_control)
         else:
             # the ControlNet's own launches on a forked stream, joined before the UNet's first pose residual add (its middle block)
             s_pose = self.pose_stream
             s_pose.wait_stream(main)
             with torch.cuda.stream(s_pose):
-                pose = pose_e.pose([self.x] * (n_pose // b), self.hint_feat, self.t_cur[:n_pose], self.kv_pose, emb=self.emb_cur_pose)
-            eps = unet.unet([self.x, self.x], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=nread,
+                pose = pose_e.pose([self.xw] * (n_pose // b), self.hint_feat, self.t_cur[:n_pose], self.kv_pose, emb=self.emb_cur_pose)
+            eps = unet.unet([self.xw, self.xw], self.t_cur, self.kv_unet, banks=banks, pose=pose, nread=nread,
                             only_mid_control=model.only_mid_control, emb=self.emb_cur_unet, pose_ready=s_pose)
             main.wait_stream(s_pose)
         if self.balance:

@@ -213,6 +213,27 @@ def counter_add(counter, delta):
     _lib.check(_lib.load().md_counter_add(_p(counter), delta, stream_ptr()), "md_counter_add")
 
 
+def gather_frames(src, dst, idx_table, counter, window, row_bytes):
+    """md_gather_frames: dst[j] = src[idx_table[counter][window][j]] (rows of row_bytes bytes); idx_table int32 [steps, windows, n]."""
+    steps, windows, n = idx_table.shape
+    _lib.check(_lib.load().md_gather_frames(_p(src), _p(dst), _p(idx_table), _p(counter), steps, windows, window, n, row_bytes,
+                                            stream_ptr()), "md_gather_frames")
+    return dst
+
+
+def cfg_scatter_add(eps_c, eps_u, ld_eps, coef, idx_table, counter, window, pred, counts, hw, c):
+    """md_cfg_scatter_add: pred[idx[j]] += e_u[j] + coef[4] (e_c[j] - e_u[j]); counts[idx[j]] += 1 (ddim.py:586-590)."""
+    steps, windows, n = idx_table.shape
+    _lib.check(_lib.load().md_cfg_scatter_add(_p(eps_c), _p(eps_u), ld_eps, _p(coef), _p(idx_table), _p(counter), steps, windows, window,
+                                              n, _p(pred), _p(counts), hw, c, stream_ptr()), "md_cfg_scatter_add")
+
+
+def window_mean(pred, counts, eps, frames, per_frame):
+    """md_window_mean: eps[f] = pred[f] / counts[f], then pred and counts are cleared (ddim.py:592-593)."""
+    _lib.check(_lib.load().md_window_mean(_p(pred), _p(counts), _p(eps), frames, per_frame, stream_ptr()), "md_window_mean")
+    return eps
+
+
 def ddim_update(eps_c, eps_u, ld_eps, x, noise, coef, x_prev, pred_x0, eps_out, batch, c, hw):
     _lib.check(_lib.load().md_ddim_update(_p(eps_c), _p(eps_u), ld_eps, _p(x), _p(noise), _p(coef), _p(x_prev),
                                           _p(pred_x0), _p(eps_out), batch, c, hw, stream_ptr()), "md_ddim_update")

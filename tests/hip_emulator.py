@@ -298,6 +298,33 @@ def counter_add(counter, delta):
     counter += delta
 
 
+def gather_frames(src, dst, idx_table, counter, window, row_bytes):
+    st = min(max(int(counter[0]), 0), idx_table.shape[0] - 1)
+    idx = idx_table[st, window].long()
+    n = idx.numel()
+    sv = src.contiguous().view(torch.uint8).reshape(-1, row_bytes)
+    dst.view(torch.uint8).reshape(-1)[:n * row_bytes].copy_(sv[idx].reshape(-1))
+    return dst
+
+
+def cfg_scatter_add(eps_c, eps_u, ld_eps, coef, idx_table, counter, window, pred, counts, hw, c):
+    st = min(max(int(counter[0]), 0), idx_table.shape[0] - 1)
+    idx = idx_table[st, window].long()
+    n = idx.numel()
+    ec = _mem(eps_c, (n, hw, c), (hw * ld_eps, ld_eps, 1)).float()
+    eu = _mem(eps_u, (n, hw, c), (hw * ld_eps, ld_eps, 1)).float()
+    pv = pred.reshape(-1, hw, c)
+    pv.index_add_(0, idx, eu + float(coef[4]) * (ec - eu))
+    counts.index_add_(0, idx, torch.ones(n))
+
+
+def window_mean(pred, counts, eps, frames, per_frame):
+    eps.reshape(frames, per_frame).copy_(pred.reshape(frames, per_frame) / counts.reshape(frames, 1))
+    pred.zero_()
+    counts.zero_()
+    return eps
+
+
 def ddim_update(eps_c, eps_u, ld_eps, x, noise, coef, x_prev, pred_x0, eps_out, batch, c, hw):
     a_t, a_prev, sigma, s1m, scale = [float(v) for v in coef]
     e = _mem(eps_c, (batch, hw, c), (hw * ld_eps, ld_eps, 1)).transpose(1, 2)
@@ -361,7 +388,7 @@ def install(monkeypatch):
     from magicdance_amd import ops, engine
     for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
                  "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
-                 "ddim_update", "Graph"):
+                 "ddim_update", "gather_frames", "cfg_scatter_add", "window_mean", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(engine, "_require_gpu", lambda device: None)
     monkeypatch.setattr(torch.cuda, "Stream", _Stream)

@@ -35,7 +35,7 @@ def test_header_symbols_are_exported_and_bound(lib_path):
     # the Python binding covers the same set (a symbol added to the header must be bound, and vice versa)
     assert sorted(_lib.SIGNATURES) == declared
     loaded = _lib.load()
-    assert loaded.md_version() == 7 and loaded.md_arch() == b"gfx950"
+    assert loaded.md_version() == 8 and loaded.md_arch() == b"gfx950"
 
 
 def test_param_structs_match_header_layout():

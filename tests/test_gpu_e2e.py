@@ -242,8 +242,10 @@ def test_wonoise_false_matches_reference_golden(dev, route):
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b1_noisy pred_x0 trajectory vs golden") <= TOL_Z
 
 
-def test_overlap_sampling_matches_reference_golden(dev):
-    """overlap_sampling (ddim.py:569-594): 16-frame windows / stride 12 from python-random offsets, generic route."""
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_overlap_sampling_matches_reference_golden(dev, route):
+    """overlap_sampling (ddim.py:569-594): 16-frame windows / stride 12 from python-random offsets -- the per-call route
+    and (round 4) the fused step graph with its device window-index table."""
     import random
     g = H.load_golden("small_b16_overlap")
     model = _model(g, dev)
@@ -253,9 +255,11 @@ def test_overlap_sampling_matches_reference_golden(dev):
     traj = []
     z, _ = model.sample_log(cond=c, batch_size=int(g["frames"]), ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
                             unconditional_guidance_scale=7, unconditional_conditioning=uc, inpaint=None, x_T=inp["x_T"].to(dev),
-                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()))
-    assert _rel(z.cpu().numpy(), g["z"], "small_b16_overlap z vs golden") <= TOL_Z
-    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], "small_b16_overlap pred_x0 trajectory vs golden") <= TOL_Z
+                            img_callback=lambda p, i: traj.append(p.detach().cpu().clone()), force_generic=(route == "generic"))
+    if route == "fused":   # (the model object is shared between tests: only the fused run can tell which route it took)
+        assert model._fused is not None and model._fused.overlap and model._fused.graph is not None
+    assert _rel(z.cpu().numpy(), g["z"], f"small_b16_overlap z vs golden ({route} route)") <= TOL_Z
+    assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"], f"small_b16_overlap pred_x0 trajectory vs golden ({route} route)") <= TOL_Z
 
 
 def test_text_context_from_the_clip_wrapper(dev):

@@ -930,3 +930,36 @@ def test_groupnorm_second_parameter_set(dev, shape):
     assert torch.equal(one, two)
     ref = F.silu(F.group_norm(_nchw32(x16[b2:], b - b2, h, w), 32, gb, bb, eps=1e-5))
     assert _err(_nchw32(one[b2:], b - b2, h, w), ref) <= 4e-3
+
+
+def test_overlap_window_ops(dev):
+    """md_gather_frames / md_cfg_scatter_add / md_window_mean (ABI v8; ddim.py:569-594 inside the fused step) against index_select /
+    index_add_ / a division, the step read from the device counter (and clamped to the table)."""
+    from magicdance_amd import ops
+    nf, hw, c, steps, nw = 23, 64, 4, 5, 2
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.stack([torch.stack([torch.randperm(nf, generator=gen)[:16] for _ in range(nw)]) for _ in range(steps)]).to(torch.int32).to(dev)
+    x = _rand((nf, c, 8, 8), 1, dev)
+    feat = _rand((nf, hw, 24), 2, dev).to(F16)
+    coef = torch.tensor([0.9, 0.8, 0.0, 0.3, 7.0], device=dev)
+    pred, counts = torch.zeros(nf, hw, c, device=dev), torch.zeros(nf, device=dev)
+    want_pred, want_counts = torch.zeros_like(pred), torch.zeros_like(counts)
+    for step in (0, 3, 9):                                    # 9: past the table -> its last row
+        counter = torch.tensor([step], dtype=torch.int32, device=dev)
+        row = idx[min(step, steps - 1)]
+        for w in range(nw):
+            xw, fw = torch.empty(16, c, 8, 8, device=dev), torch.empty(16, hw, 24, dtype=F16, device=dev)
+            ops.gather_frames(x, xw, idx, counter, w, c * 64 * 4)
+            ops.gather_frames(feat, fw, idx, counter, w, hw * 24 * 2)
+            assert torch.equal(xw, x[row[w].long()]) and torch.equal(fw, feat[row[w].long()])
+            ec, eu = _rand((16, hw, c), 10 + w, dev), _rand((16, hw, c), 20 + w, dev)
+            ops.cfg_scatter_add(ec, eu, c, coef, idx, counter, w, pred, counts, hw, c)
+            want_pred.index_add_(0, row[w].long(), eu + 7.0 * (ec - eu))
+            want_counts.index_add_(0, row[w].long(), torch.ones(16, device=dev))
+    assert torch.allclose(pred, want_pred, atol=1e-5) and torch.equal(counts, want_counts)
+    seen = counts > 0
+    counts[~seen] = 1.0                                       # (the sampler's windows cover every frame; here some frames may be unvisited)
+    eps = torch.empty_like(pred)
+    ops.window_mean(pred, counts, eps, nf, hw * c)
+    want = want_pred / torch.where(seen, want_counts, torch.ones_like(want_counts)).reshape(-1, 1, 1)
+    assert torch.allclose(eps, want, atol=1e-5) and float(pred.abs().max()) == 0.0 and float(counts.abs().max()) == 0.0

@@ -298,10 +298,14 @@ def test_fused_route_falls_back_when_the_table_does_not_fit(monkeypatch):
     assert model._fused is None and _rel(z_g.numpy(), z_f.numpy()) <= 1e-2
 
 
-def test_overlap_sampling_route_matches_reference_golden(monkeypatch):
-    """overlap_sampling temporal windows (ddim.py:569-594), generic route, python-random offsets seeded as in the fixture."""
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_overlap_sampling_route_matches_reference_golden(monkeypatch, route):
+    """overlap_sampling temporal windows (ddim.py:569-594), python-random offsets seeded as in the fixture -- on the
+    per-call route and (round 4) inside the fused step: window index table, md_gather_frames / md_cfg_scatter_add / md_window_mean."""
     import random
+    from magicdance_amd import ddim
     hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
     g = H.load_golden("small_b16_overlap")
     model = H.build_hip_model(int(g["geo_model_channels"]), int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu",
                               image_size=int(g["side"]))
@@ -310,9 +314,14 @@ def test_overlap_sampling_route_matches_reference_golden(monkeypatch):
     traj = []
     z, _ = model.sample_log(cond=inp["c"], batch_size=int(g["frames"]), ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
                             unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"],
-                            img_callback=lambda p0, i: traj.append(p0.clone()))
+                            img_callback=lambda p0, i: traj.append(p0.clone()), force_generic=(route == "generic"))
+    assert (model._fused is not None) == (route == "fused")
     assert _rel(z.numpy(), g["z"]) <= 2e-2
     assert _rel(torch.stack(traj).numpy(), g["pred_x0_traj"]) <= 2e-2
+    if route == "fused":
+        st = model._fused
+        assert st.overlap and st.nf == int(g["frames"]) and st.b == 16 and tuple(st.ov_idx.shape) == (int(g["steps"]), 2, 16)
+        assert float(st.ov_counts.abs().max()) == 0.0 and float(st.ov_pred.abs().max()) == 0.0   # cleared for the next step
 
 
 def test_fp8_attention_path_host_logic(monkeypatch):

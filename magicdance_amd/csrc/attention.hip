@@ -1327,7 +1327,7 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
     if ((p->k0_batch_stride & 15) || (p->vt0_batch_stride & 15) || (p->k1_batch_stride & 15) || (p->vt1_batch_stride & 15)) return MD_ERR_BAD_ARG;
     // self / bank attention at d = 40 / 80: the pipelined loop on fp8 operands (round 4); everything else (77-key cross attention,
     // d = 160, the power-of-two test head sizes) stays on the plain 2-stage kernel
-    if (p->n0 == p->nq && !getenv("MD_FP8_V2")) {
+    if (p->n0 == p->nq) {
       const long long wg128f = (long long)((p->nq + 127) / 128) * p->heads * p->batch;
       if (p->d == 40) return wg128f >= 512 ? launch_v3<40, 2, 1, true>(g, s) : launch_v3<40, 1, 1, true>(g, s);
       if (p->d == 80) return launch_v3<80, 1, 1, true>(g, s);

@@ -1,7 +1,11 @@
 """Round-4 attention A/B (GPU box only): the round-3 steady loop (MD_ATTN_V=0) against the round-4 form (MD_ATTN_V=1) and its
 ablations (MD_ATTN_ABL bit mask: 1 no exp2, 2 no row-max chain, 4 no lane-group exchange, 8 no loads / barrier, 16 s_setprio around
 the MFMA blocks, 32 no PV MFMAs, 64 no QK^T MFMAs) -- correctness at the production shapes (128-row query blocks are not reached by
-the small unit-test shapes), then interleaved timing rounds in ONE process."""
+the small unit-test shapes), then interleaved timing rounds in ONE process.
+NOTE: the MD_ATTN_V / MD_ATTN_ABL switches this script flips existed only on the day of the run (gpurun r4i): the round-4 loop is
+the only loop now, so every 'variant' below times the same kernel.  Kept as the record of how profiles/round4_attention_loop_ab.txt was
+produced and for its helpers (make / reference / time_us / tf), which tools/attn_fp8_ab.py imports.
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

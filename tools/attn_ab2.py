@@ -1,5 +1,7 @@
 """Round-4 attention: polynomial-exp2 variants of the round-4 loop (MD_ATTN_ABL 128 = all score pairs, 256 = every second pair)
-against the v_exp_f32 form -- accuracy at the production shape, then interleaved timing.  GPU box only."""
+against the v_exp_f32 form -- accuracy at the production shape, then interleaved timing.  GPU box only.
+NOTE: MD_ATTN_ABL (128 / 256 = polynomial exp2) existed only on the day of the run (gpurun r4j); the variants were removed.
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from attn_ab import *   # noqa: F401,F403

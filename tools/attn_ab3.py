@@ -1,4 +1,6 @@
-"""Round-4 attention loop on the other production shapes (64-row query blocks at d = 40, d = 80): V=0 vs V=1, interleaved.  GPU box only."""
+"""Round-4 attention loop on the other production shapes (64-row query blocks at d = 40, d = 80): V=0 vs V=1, interleaved.  GPU box only.
+NOTE: MD_ATTN_V existed only on the day of the run (gpurun r4k).
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from attn_ab import *   # noqa: F401,F403

@@ -1,6 +1,8 @@
 """fp8 attention (BASELINE configs[4]): the pipelined loop on e4m3 operands with the piecewise-linear exp2 (default since round 4)
 against the plain 2-stage fp8 kernel (MD_FP8_V2=1) and the fp16 kernel -- accuracy vs fp32 attention over the same e4m3 operands,
-then interleaved timing.  GPU box only."""
+then interleaved timing.  GPU box only.
+NOTE: MD_FP8_V2 (the 2-stage fp8 kernel for every shape) existed only on the day of the run (gpurun r4t).
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from attn_ab import *   # noqa: F401,F403

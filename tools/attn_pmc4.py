@@ -1,4 +1,6 @@
-"""One d = 40 self + bank attention launch set per loop form (MD_ATTN_V = 0, 1) at 16 samples, for rocprofv3 --pmc; GPU box only."""
+"""One d = 40 self + bank attention launch set per loop form (MD_ATTN_V = 0, 1) at 16 samples, for rocprofv3 --pmc; GPU box only.
+NOTE: MD_ATTN_V existed only on the day of the run (gpurun r4i); both 'forms' are the shipped kernel now.
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

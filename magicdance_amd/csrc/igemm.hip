@@ -428,6 +428,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const IgemmArgs g) {
         const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
+          // the n-waves of a wave row hold the SAME A fragments: each takes the statistics of every WAVES_N-th one (the epilogue
+          // exchanges them through LDS) -- these v_dot2 serialise with the MFMAs of the SIMD, halving them is worth 6-10 % of the GEMM
+          if (WAVES_N > 1 && (i % WAVES_N) != wn) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};

@@ -229,6 +229,31 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& g, char* const s
       }
     }
   }
+  // ---- folded LayerNorm: the n-waves of a wave row computed the row statistics of alternating A fragments -> exchange ------------
+  if constexpr (LN && WAVES_N > 1) {
+    static_assert(WAVES_M * MF * 2 * 64 * 4 <= LDS_TOTAL, "statistics exchange fits the stage memory");
+    const int wave_ = tid >> 6;
+    const int xm = wave_ % WAVES_M, xn = wave_ / WAVES_M;
+    float* const ex = reinterpret_cast<float*>(smem);   // [wave row][fragment][sum | sumsq][lane]
+    __syncthreads();   // every wave is done with the stage memory (and with the k-group reduction buffers)
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < MF; ++j)
+        if ((j % WAVES_N) == xn) {
+          ex[((xm * MF + j) * 2 + 0) * 64 + lane] = ln_sum[j];
+          ex[((xm * MF + j) * 2 + 1) * 64 + lane] = ln_sq[j];
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < MF; ++j)
+        if ((j % WAVES_N) != xn) {
+          ln_sum[j] = ex[((xm * MF + j) * 2 + 0) * 64 + lane];
+          ln_sq[j] = ex[((xm * MF + j) * 2 + 1) * 64 + lane];
+        }
+    }
+  }
   const bool epi = kg == 0;   // the epilogue belongs to group 0; the other groups only keep the (uniform) barriers below company
 
   // ---- epilogue ---------------------------------------------------------------------------------------

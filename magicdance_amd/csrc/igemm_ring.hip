@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void igemm_ring_kernel
       const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
+        if (WAVES_N > 1 && (i % WAVES_N) != wn) continue;   // (the n-waves of a wave row share the statistics work: igemm.hip)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const h2v p = {af[i][2 * e], af[i][2 * e + 1]};

@@ -10,10 +10,18 @@ CASES = [  # B, H, W, Cin, Cout, ks, cfg, split
     (16, 64, 64, 640, 640, 3, 12, 1), (16, 64, 64, 640, 640, 3, 25, 1),
     (16, 64, 64, 1280, 1280, 1, 12, 1), (16, 64, 64, 1280, 1280, 1, 25, 1),
     (1, 16, 16, 1280, 1280, 3, 15, 8),
+    # round 4: the ring form on the same shapes (4-wave 128x160, 8-wave 256x160 plain / register-pipelined, 8-wave 128x160), the 8x8 level
+    (16, 64, 64, 640, 640, 3, 49, 1), (16, 64, 64, 640, 640, 3, 55, 1), (16, 64, 64, 640, 640, 3, 60, 1), (16, 64, 64, 640, 640, 3, 61, 1),
+    (16, 64, 64, 1280, 1280, 1, 49, 1),
+    (3, 8, 8, 1280, 1280, 3, 15, 4), (3, 8, 8, 1280, 1280, 3, 42, 4),
 ]
 for (b, h, w, cin, cout, k, cfg, sp) in CASES:
     x = torch.randn(b, h * w, cin, device=dev).to(F16); wt = (torch.randn(cout, k * k * cin, device=dev) * 0.02).to(F16)
     out = torch.empty(b, h * w, cout, dtype=F16, device=dev)
+    tiled = cin % 64 == 0 and cout % 16 == 0 and not os.environ.get("PMC_ROW_MAJOR")   # the engine stores these weights tiled (md_igemm_params.w_tiled)
+    if tiled:
+        wt = ops.tile_weights(wt, k)
     for _ in range(3):
-        ops.igemm(x, wt, cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, out=out, ws=ws, force_cfg=cfg, force_splitk=sp)
+        ops.igemm(x, wt, cout, batch=b, hin=h, win=w, hout=h, wout=w, c0=cin, ksize=k, out=out, ws=ws, force_cfg=cfg, force_splitk=sp,
+                  w_tiled=tiled)
     torch.cuda.synchronize()

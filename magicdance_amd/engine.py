@@ -373,7 +373,7 @@ class NetEngine:
         buf = _WS.get(key)
         if buf is None:
             buf = _WS[key] = torch.empty(96 << 20, dtype=torch.uint8, device=self.device)
-            buf[:16384].zero_()  # split-K arrival counters (md_igemm re-arms them after every use)
+            buf[:16384].zero_()  # (defined contents for the first bytes; the slabs are fully written before they are read)
         return buf
 
     _WANT = {}

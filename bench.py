@@ -7,9 +7,10 @@ update per step) and the first-stage (VAE) decode of the frames, latents in -> d
 HBM before the timed region; nothing is cached across batches (the table is recomputed for every batch).
 N=1 default workload = BASELINE.json configs[1]: single 512x512 frame, 50-step DDIM, full Appearance+Pose ControlNet,
 fp16, random-init (seeded synthetic) SD-1.5-geometry weights.  N>1: one process per GPU (torch.distributed over RCCL),
-frames sharded across ranks (weak scaling: `--frames-per-gpu` each), the reference-image KV table computed in equal row
-blocks (one block of timesteps per rank) and exchanged with one RCCL all-gather per table segment, decoded frames
-all-gathered.
+frames sharded across ranks (weak scaling: `--frames-per-gpu` each -- the SAME one frame per GPU and batch as at N=1, so
+that the per-N values compare directly), the reference-image KV table computed in equal row blocks (one block of
+timesteps per rank) and exchanged with one RCCL all-gather per table segment, decoded frames all-gathered.  The
+8-frames-per-GPU shapes ride along as `extra`: configs[2] at N=1, configs[3] (8 N frames sharded N-way) at N>1.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (igemm = the dominant kernel family, HIP-event timed per
 launch on the launch stream) and "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample).
@@ -220,9 +221,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5, help="timed frame-batches (each = a full DDIM loop)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-gpu", type=int, default=None,
-                    help="frames per GPU per batch; default 1 at --gpus 1 (BASELINE configs[1]), 8 at --gpus N > 1 (configs[3]: "
-                         "8 frames per GPU as one batch, 64 frames on 8 GPUs)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra configs[2] line (8 frames as one batch) at --gpus 1")
+                    help="frames per GPU per batch; default 1 at every --gpus N (BASELINE configs[1] per GPU: weak scaling with fixed "
+                         "per-GPU work); 8 = the configs[2] / configs[3] shape (8 frames per GPU as one batch, 64 frames on 8 GPUs)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra line: configs[2] (8 frames as one batch) at --gpus 1, the configs[3] shape (8 frames per GPU) at N > 1")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--size", type=int, default=64, help="latent side (64 = 512x512)")
     ap.add_argument("--sequence", type=int, default=0,
@@ -236,6 +238,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every DDIM step un-captured (same launches, no HIP graph): the form the rocprofv3 --pmc passes of "
                          "tools/run_profiles.sh run on (the counter tool does not survive graph replays of the linear step graph)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="at --gpus 1: run the MULTI-GPU code path of this script (process group over RCCL, sharded reference-KV table with its "
+                         "all-gathers, barriers / max-over-ranks timing, the N > 1 extra line) on a 1-rank process group -- what a GPU box with "
+                         "one device can test of it (tests/test_gpu_rccl.py)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="run ONLY the rank launch / join protocol (self-spawn of --gpus ranks, process group, join count) and print "
                          "its JSON line: no model, no kernels (gloo when there is no GPU -- the CPU test tier drives this)")
@@ -265,7 +271,10 @@ def main():
     dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
     dist = None
     joined = 1
-    if world > 1:
+    sharded_1 = args.force_sharded and world == 1
+    if sharded_1 and "MASTER_ADDR" not in os.environ:   # a 1-rank group outside torchrun: the env:// rendezvous wants these
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if world > 1 or sharded_1:
         import torch.distributed as dist
         if have_gpu:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
@@ -291,10 +300,15 @@ def main():
         engine.ATTN_FP8 = True   # read when the engines pack their weights / allocate their K / V^T buffers
     state0 = gpu_state() if rank == 0 else None
     model = build_model(dev, args.size)
-    fpg = args.frames_per_gpu if args.frames_per_gpu else (1 if world == 1 else 8)
-    cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get((fpg, world), "configs[3]" if (fpg == 8 and world > 1) else "custom")
+    # per-GPU work is FIXED as N grows (weak scaling of the headline config): one frame per GPU and batch at every N, the frames of
+    # a batch sharing one reference image (whose reference-KV table the ranks compute in shares and all-gather).  The configs[3]
+    # shape (8 frames per GPU) rides along as `extra` at N > 1, as configs[2] does at N = 1.
+    fpg = args.frames_per_gpu if args.frames_per_gpu else 1
+    cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get(
+        (fpg, world), "configs[3]" if (fpg == 8 and world > 1) else (f"configs[1] x {world} GPUs" if fpg == 1 else "custom"))
     inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
-    runner = parallel.FrameShardedSampler(model, rank=rank, world=world)
+    runner = parallel.FrameShardedSampler(model, rank=rank, world=world, force_sharded=sharded_1)
+    multi = dist is not None   # world > 1, or the 1-rank stand-in of --force-sharded
     if args.no_graph:
         # counter runs: every launch un-captured AND on ONE stream (the reference-KV table pass no longer overlaps the first steps;
         # same launches, same arguments, same order per stream) -- rocprofv3's counter collection serialises kernels anyway
@@ -345,11 +359,36 @@ def main():
                       "parallelism": f"frame-shard x{world}"}}
     if rank == 0:
         out["gpu_state"] = {"before_load": state0, "after_timed_region": gpu_state(), "source": "rocm-smi --showclocks --showtemp --showpower"}
-    if world > 1:
-        # the N = 1 line's `value` is configs[1] (ONE frame per batch, the headline metric); the per-GPU work of this line is the
-        # N = 1 line's `extra` entry -- that is the one-GPU figure a scaling efficiency of this line is to be taken against
-        out["scaling_reference"] = (f"per-GPU work = {fpg} frame(s) as one batch: compare with the N=1 line's extra['configs[2]'].value "
-                                    "(8 frames per batch on one GPU), not with its value (configs[1], 1 frame per batch)")
+    if multi:
+        out["scaling_reference"] = (
+            f"per-GPU work = {fpg} frame(s) as one batch" +
+            (": the N=1 line's `value` (configs[1]) is the one-GPU figure of this line; the reference-KV table of the shared reference "
+             "image is computed in 1/N shares and all-gathered, so the per-GPU work even shrinks slightly with N" if fpg == 1 else
+             ": compare with the N=1 line's extra['configs[2]'].value (8 frames per batch on one GPU) when frames_per_gpu is 8"))
+    if multi and fpg == 1 and not args.sequence and not args.no_extra:
+        # extra line at N > 1: the BASELINE configs[3] shape (8 frames per GPU as one batch, 8 N frames sharded N-way), same timing
+        # protocol (barrier + synchronize on both sides, max over ranks), 1 warm-up + 3 timed batches.  EVERY rank runs this leg.
+        p8 = synthetic.synth_inputs((args.size, args.size), frames=8 * world, seed=0, device=dev)
+        pose8 = p8["pose"][rank * 8:(rank + 1) * 8].contiguous()
+        x8 = p8["x_T"].repeat(8, 1, 1, 1)
+        runner.sample(pose8, ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
+        torch.cuda.synchronize()
+        dist.barrier()
+        n8 = 3
+        t0 = time.time()
+        for _ in range(n8):
+            runner.sample(pose8, ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t8 = torch.tensor([time.time() - t0], device=dev)
+        dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+        d8 = float(t8.item()) / n8
+        out["extra"] = {("configs[3]" if world == 8 else f"configs[3] shape on {world} GPUs"): {
+            "workload": f"{8 * world} frames sharded {world}-way (8 frames per GPU as one batch), {8 * args.size}x{8 * args.size}, "
+                        f"{args.ddim_steps}-step DDIM, " + ("latents out" if args.no_decode else "decoded frames all-gathered"),
+            "value": 8 * world / d8, "unit": "frames/s", "ms_per_step": 1e3 * d8, "ms_per_ddim_step": 1e3 * d8 / args.ddim_steps,
+            "steps": n8, "warmup": 1, "n_gpus": world,
+            "scaling_reference": "the N=1 line's extra['configs[2]'].value (8 frames per batch on one GPU)"}}
     if rank == 0 and not args.no_roofline:
         # every kernel family over ONE batch of frames = the reference-KV table pass (once) + S x one DDIM step: per-launch
         # HIP events on un-captured launches (ms_eager_events, includes eager launch latency) and, for igemm / attention,
@@ -364,7 +403,7 @@ def main():
             pi = synthetic.synth_inputs((args.size, args.size), frames=bb, seed=0, device=dev)
             nets[f"B{bb}"] = runner.network_pass_times(pi["pose"], ctx, ref, pi["x_T"].repeat(bb, 1, 1, 1), ddim_steps=args.ddim_steps)
         out["unet_ms_per_step"] = nets
-    if rank == 0 and world == 1 and fpg == 1 and not args.sequence and not args.no_extra:
+    if rank == 0 and not multi and fpg == 1 and not args.sequence and not args.no_extra:
         # extra line: BASELINE configs[2] (8 frames as one batch on one GPU -- "the roofline run"), same timing protocol, 1 warm-up +
         # 5 timed batches, with its own roofline blocks
         p8 = synthetic.synth_inputs((args.size, args.size), frames=8, seed=0, device=dev)
@@ -384,15 +423,22 @@ def main():
             fam8 = runner.profile_one_step(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
             e8["roofline"], e8["roofline_attention"], e8["families_ms_per_batch"] = roofline_blocks(fam8, args.no_decode, False)
         out["extra"] = {"configs[2]": e8}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         z_one = runner.sample(pose[:1], ctx, ref, x_T[:1], ddim_steps=args.ddim_steps, scale=7.0) if not args.no_decode else None
         out["cpu_baseline"] = cpu_baseline(model, inp, args.size, z_one,
                                            None if z_one is None else model.decode_first_stage(z_one))
-    if rank == 0:
-        print(json.dumps(out))
+    # the ONE JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, whose buffer (stdout is a pipe
+    # under the driver) would otherwise be flushed at exit, i.e. AFTER a line Python printed earlier -- every rank empties its
+    # buffers before the last barrier, rank 0 prints after the group is gone
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     if dist is not None:
         dist.barrier()   # rank 0 may still have been profiling: leave the group together
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -92,3 +92,27 @@ def test_full_size_sharded_route_one_rank(dev, group):
     z_ref = parallel.FrameShardedSampler(model, rank=0, world=1).sample(pose, ctx, ref, xs, ddim_steps=50, scale=7.0)
     err = float((z - z_ref).abs().max() / z_ref.abs().max())
     assert bool(torch.isfinite(z).all()) and err <= 1.5e-3, err   # appearance batches of 16 (+9) vs 16/16/16/2 rows: rounding only
+
+
+def test_bench_multi_gpu_code_path_on_a_one_rank_group(dev):
+    """bench.py's N > 1 branches (process group, join count, barriers, max-over-ranks timing, the sharded sampler, the configs[3]-
+    shaped `extra` leg run by every rank, rank-0 epilogue, group teardown) cannot run on a one-GPU box as N > 1 -- ``--force-sharded``
+    runs exactly those branches on a 1-rank RCCL group.  A subprocess: bench.py owns its process group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--size", "16", "--ddim-steps", "6",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("{"), "the JSON line must be the LAST line on stdout (after RCCL's banner): " + r.stdout[-500:]
+    line = json.loads(last)
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["frames_per_gpu"] == 1 and "scaling_reference" in line
+    (name, e8), = line["extra"].items()
+    assert "configs[3]" in name and e8["n_gpus"] == 1 and e8["value"] > 0 and e8["steps"] == 3

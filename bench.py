@@ -215,6 +215,15 @@ def roofline_blocks(fam, no_decode, pmc_ok):
     return roof, roof_at, fams
 
 
+def workload_for(frames_per_gpu, world):
+    """(frames per GPU and batch, BASELINE.json config name) of a run on ``world`` GPUs: ONE frame per GPU at every N unless asked
+    otherwise (weak scaling: the per-N values of the default runs compare directly)."""
+    fpg = frames_per_gpu if frames_per_gpu else 1
+    name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get(
+        (fpg, world), "configs[3]" if (fpg == 8 and world > 1) else (f"configs[1] x {world} GPUs" if fpg == 1 else "custom"))
+    return fpg, name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,9 +312,7 @@ def main():
     # per-GPU work is FIXED as N grows (weak scaling of the headline config): one frame per GPU and batch at every N, the frames of
     # a batch sharing one reference image (whose reference-KV table the ranks compute in shares and all-gather).  The configs[3]
     # shape (8 frames per GPU) rides along as `extra` at N > 1, as configs[2] does at N = 1.
-    fpg = args.frames_per_gpu if args.frames_per_gpu else 1
-    cfg_name = {(1, 1): "configs[1]", (8, 1): "configs[2]"}.get(
-        (fpg, world), "configs[3]" if (fpg == 8 and world > 1) else (f"configs[1] x {world} GPUs" if fpg == 1 else "custom"))
+    fpg, cfg_name = workload_for(args.frames_per_gpu, world)
     inp = synthetic.synth_inputs((args.size, args.size), frames=fpg * world, seed=0, device=dev)
     runner = parallel.FrameShardedSampler(model, rank=rank, world=world, force_sharded=sharded_1)
     multi = dist is not None   # world > 1, or the 1-rank stand-in of --force-sharded

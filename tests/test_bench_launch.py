@@ -33,3 +33,15 @@ def test_bench_single_rank_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1
+
+
+def test_per_gpu_work_is_the_same_at_every_n():
+    """weak scaling of the headline config: the default run keeps ONE frame per GPU and batch at N = 1, 2, 4, 8 (the driver computes
+    its scaling efficiency from the per-N values); the 8-frames-per-GPU shapes are explicit"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [bench.workload_for(None, n)[0] for n in (1, 2, 4, 8)] == [1, 1, 1, 1]
+    assert bench.workload_for(None, 1)[1] == "configs[1]" and bench.workload_for(8, 1)[1] == "configs[2]"
+    assert bench.workload_for(8, 8)[1] == "configs[3]" and "configs[1]" in bench.workload_for(None, 8)[1]

@@ -96,6 +96,8 @@ class ClipTextEngine:
         dev, c, H, dh, F16 = self.device, self.c, self.heads, self.dh, torch.float16
         ids = ids.to(dev)
         b, n = ids.shape
+        if n > self.pos.shape[0]:
+            raise ValueError(f"{n} tokens, the text tower has {self.pos.shape[0]} positions")
         new = lambda *shape: torch.empty(shape, dtype=F16, device=dev)   # noqa: E731
         x = new(b, n, c)
         ops.add_f16(self.tok.index_select(0, ids.reshape(-1)), self.pos[:n], x, b * n * c, b_period=n * c)

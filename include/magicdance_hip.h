@@ -154,6 +154,43 @@ int md_igemm_config_info(int32_t cfg, int32_t info[8]);
 int64_t md_igemm_workspace_bytes(const md_igemm_params* p);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * md_ff_block (ABI v9): the row-local tail of a BasicTransformerBlock as ONE launch,
+ *   t2  = attn Wo^T + bo + x (+ x_lo)                       (only when attn != NULL: to_out of attn2 + residual)
+ *   out = GEGLU(LayerNorm(t2)) W2^T + b2 + t2               (out_lo = what the fp16 rounding of out dropped)
+ * with the [M][4C] GEGLU hidden activation, the normalised rows and t2 kept inside the CU (a BM x C tile of the stream resident
+ * in LDS, the weights streamed through an LDS ring; ffblock.hip).
+ * Replaces: CrossAttention.to_out + residual (ldm/modules/attention.py:196-199, 318), nn.LayerNorm norm3 (:272, 319),
+ * FeedForward = GEGLU + Linear (:50-77) + residual (:319) -- i.e. the md_igemm launches {to_out, GEGLU projection with folded
+ * LayerNorm, feed-forward output} of one transformer block.  c must be 320 or 640 (SD-1.5's 64x64 / 32x32 levels);
+ * weights in the tiled storage form of md_igemm_params.w_tiled; w1 / s1 / s0 exactly as md_igemm takes them for the folded
+ * GEGLU projection (rows interleaved a | gate in groups of 16, W' = W diag(gamma), s1[n] = sum_k W'[n][k], s0[n] = W beta + b).
+ * Rows >= m_split use the second parameter set (as md_igemm batch2).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;           /* fp16 [m][c]: the residual stream entering the block tail (hi term) */
+  const void* x_lo;        /* fp16 [m][c] second term of the stream, or NULL */
+  const void* attn;        /* fp16 [m][c] attention output feeding to_out, or NULL (then x itself is the feed-forward input) */
+  int32_t m, c;
+  const void* wo;          /* fp16 [c][c] tiled; with attn */
+  const float* bo;         /* fp32 [c] */
+  const void* w1;          /* fp16 [8c][c] tiled, LayerNorm-folded GEGLU projection */
+  const float* s1;         /* fp32 [8c] */
+  const float* s0;         /* fp32 [8c] */
+  float ln_eps;
+  const void* w2;          /* fp16 [c][4c] tiled */
+  const float* b2;         /* fp32 [c] */
+  void* out;               /* fp16 [m][c] */
+  void* out_lo;            /* fp16 [m][c] or NULL */
+  /* second parameter set (NULL: one set) */
+  const void* wo_2; const float* bo_2; const void* w1_2; const float* s1_2; const float* s0_2; const void* w2_2; const float* b2_2;
+  int32_t m_split;
+  int32_t force_bm;        /* 0: auto; 32 / 64 / 128 rows per workgroup (tests / tuning; 128 only for c = 320) */
+} md_ff_block_params;
+int md_ff_block(const md_ff_block_params* p, void* stream);
+/* 1 when md_ff_block serves this (rows, channels) */
+int md_ff_block_supported(int32_t m, int32_t c);
+
+/* ---------------------------------------------------------------------------------------------------------
  * md_attention: flash-style scaled-dot-product attention with up to two K/V segments (self tokens + appearance
  * bank tokens), online softmax in fp32, MFMA QK^T and PV.
  *   out[b, i, h*d:(h+1)*d] = softmax_j( q_i . k_j * scale ) v_j,   j over segment 0 then segment 1

@@ -32,6 +32,16 @@ class IgemmParams(C.Structure):
     ]
 
 
+class FfBlockParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_lo", C.c_void_p), ("attn", C.c_void_p), ("m", C.c_int32), ("c", C.c_int32),
+        ("wo", C.c_void_p), ("bo", C.c_void_p), ("w1", C.c_void_p), ("s1", C.c_void_p), ("s0", C.c_void_p),
+        ("ln_eps", C.c_float), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p), ("out_lo", C.c_void_p),
+        ("wo_2", C.c_void_p), ("bo_2", C.c_void_p), ("w1_2", C.c_void_p), ("s1_2", C.c_void_p), ("s0_2", C.c_void_p),
+        ("w2_2", C.c_void_p), ("b2_2", C.c_void_p), ("m_split", C.c_int32), ("force_bm", C.c_int32),
+    ]
+
+
 class AttentionParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("q_batch_stride", C.c_int64), ("ld_q", C.c_int32),
@@ -65,6 +75,8 @@ SIGNATURES = {
     "md_igemm": (C.c_int, [C.POINTER(IgemmParams), _vp]),
     "md_igemm_workspace_bytes": (_i64, [C.POINTER(IgemmParams)]),
     "md_igemm_config_info": (C.c_int, [_i32, C.POINTER(_i32 * 8)]),
+    "md_ff_block": (C.c_int, [C.POINTER(FfBlockParams), _vp]),
+    "md_ff_block_supported": (C.c_int, [_i32, _i32]),
     "md_attention": (C.c_int, [C.POINTER(AttentionParams), _vp]),
     "md_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), _vp]),
     "md_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),

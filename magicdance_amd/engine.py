@@ -82,6 +82,9 @@ _RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
 # GroupNorm statistics from the producing conv's epilogue (md_igemm gn_part -> md_groupnorm part0 / part1).  MD_GN_FUSE=0: every
 # GroupNorm computes its own statistics (A/B, and the parity reference of the fused form in tests/test_gpu_e2e.py).
 _GN_FUSE = os.environ.get("MD_GN_FUSE", "1") != "0"
+# Transformer-block tail (attn2.to_out + residual, norm3, GEGLU, feed-forward output + residual) as ONE launch (md_ff_block) at these
+# channel counts; MD_FF_BLOCK=0: the three md_igemm launches (A/B and parity cross-check).
+_FF_BLOCK = tuple(int(v) for v in os.environ.get("MD_FF_BLOCK", "320").split(",") if v.strip() not in ("", "0"))
 # fp8 attention path (BASELINE configs[4]): the self / bank attention's K and V^T are written as OCP e4m3 bytes by the projection
 # GEMMs and md_attention runs its contractions on the fp8 MFMA (q and P converted in registers).  Off by default (the fp16 path is
 # the parity path); bench.py --fp8-attention / MD_ATTN_FP8=1 switch it on BEFORE the engines are built.
@@ -643,6 +646,11 @@ class NetEngine:
             assert bc == 1 or bc == b, "context batch must be 1 or match the sample batch"
             att2 = self.attention(q2.t, c, kc, c, vtc, ldvc, tk, b, n, heads, dh, k0_bs=(0 if bc == 1 else tk * c),
                                   vt0_bs=(0 if bc == 1 else c * ldvc))
+            if c in _FF_BLOCK and "ff1_ln" in blk and _RES_LO and ops.ff_block_supported(b * n, c):
+                # to_out + residual, norm3, GEGLU, feed-forward output + residual as ONE launch: the stream tile stays in LDS
+                # (md_ff_block; attention.py:318-319)
+                t = self.ff_tail(blk, att2, t, b, n, c)
+                continue
             t = self.conv(Act(att2, b, 1, n, c), blk["o2_w"], c, k=1, bias=blk["o2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
             # GEGLU feed-forward (attention.py:50-77, 319)
             if "ff1_ln" in blk:
@@ -654,6 +662,24 @@ class NetEngine:
             t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
         t = Act(t.t, b, x.h, x.w, c)
         return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True, stats=True)
+
+    def ff_tail(self, blk, att2, t, b, n, c):
+        """x = attn2.to_out(att2) + x; x = ff(norm3(x)) + x (attention.py:318-319) through md_ff_block.  ``t``: the stream entering
+        the cross-attention output projection (Act with its second term)."""
+        a = self.arena
+        out, out_lo = a.alloc((b, n, c), F16), a.alloc((b, n, c), F16)
+        wl, s1, s0 = blk["ff1_ln"]
+        names = dict(w1=wl, s1=s1, s0=s0, w2=blk["ff2_w"], b2=blk["ff2_b"], wo=blk["o2_w"], bo=blk["o2_b"])
+        set2, m_split = None, 0
+        if isinstance(wl, Dual):
+            assert self._batch2 is not None
+            set2 = {k: v.b for k, v in names.items()}
+            names = {k: v.a for k, v in names.items()}
+            m_split = self._batch2 * n
+        assert all(is_tiled(names[k]) for k in ("w1", "w2", "wo"))
+        ops.ff_block(t.t, out, m=b * n, c=c, x_lo=t.lo, out_lo=out_lo, attn=att2, ln_eps=1e-5, set2=set2, m_split=m_split, **names)
+        _chk(out, f"ff_block M={b * n} c={c}")
+        return Act(out, b, 1, n, c, out_lo)
 
     def _project_bank(self, blk, bank, k_out, vt_out):
         bb, nb, c = bank.b, bank.hw, bank.c

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import IgemmParams, AttentionParams, GroupNormParams, MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU  # noqa: F401
+from ._lib import IgemmParams, AttentionParams, GroupNormParams, FfBlockParams, MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU  # noqa: F401
 
 
 def stream_ptr():
@@ -80,6 +80,32 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     if RECORD is not None:
         m = batch * hout * wout
         RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8, set2, gn_part)))
+    return out
+
+
+def ff_block_supported(m, c):
+    """md_ff_block_supported: does the fused transformer-block tail serve [m, c] token matrices?"""
+    return bool(_lib.load().md_ff_block_supported(int(m), int(c)))
+
+
+def ff_block(x, out, *, m, c, w1, s1, s0, w2, b2, ln_eps=1e-5, x_lo=None, out_lo=None, attn=None, wo=None, bo=None, set2=None,
+             m_split=0, force_bm=0):
+    """See md_ff_block: out = GEGLU(LayerNorm(t2)) W2^T + b2 + t2 with t2 = attn Wo^T + bo + x (+ x_lo) when ``attn`` is given,
+    else t2 = x (+ x_lo).  Weights in the tiled storage form; ``set2`` = dict(w1, s1, s0, w2, b2[, wo, bo]) for rows >= m_split."""
+    lib = _lib.load()
+    p = FfBlockParams()
+    p.x, p.x_lo, p.attn, p.m, p.c = _p(x), _p(x_lo), _p(attn), int(m), int(c)
+    p.wo, p.bo, p.w1, p.s1, p.s0, p.ln_eps = _p(wo), _p(bo), _p(w1), _p(s1), _p(s0), float(ln_eps)
+    p.w2, p.b2, p.out, p.out_lo = _p(w2), _p(b2), _p(out), _p(out_lo)
+    if set2 is not None:
+        p.w1_2, p.s1_2, p.s0_2, p.w2_2, p.b2_2 = _p(set2["w1"]), _p(set2["s1"]), _p(set2["s0"]), _p(set2["w2"]), _p(set2["b2"])
+        p.wo_2, p.bo_2 = _p(set2.get("wo")), _p(set2.get("bo"))
+        p.m_split = int(m_split)
+    p.force_bm = int(force_bm)
+    _lib.check(lib.md_ff_block(C.byref(p), stream_ptr()), "md_ff_block")
+    if RECORD is not None:
+        RECORD.append(("igemm", lib.md_ff_block, p, 2.0 * m * (12.0 * c * c + (c * c if attn is not None else 0.0)),
+                       (x, x_lo, attn, out, out_lo, w1, s1, s0, w2, b2, wo, bo, set2)))
     return out
 
 

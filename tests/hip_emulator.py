@@ -123,6 +123,43 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
     return out
 
 
+def ff_block_supported(m, c):
+    return c % 64 == 0 and m > 0   # (the emulation is generic; the kernel serves 320 / 640)
+
+
+def ff_block(x, out, *, m, c, w1, s1, s0, w2, b2, ln_eps=1e-5, x_lo=None, out_lo=None, attn=None, wo=None, bo=None, set2=None,
+             m_split=0, force_bm=0):
+    """md_ff_block: [to_out + residual ->] LayerNorm-folded GEGLU projection -> feed-forward output + residual"""
+    from magicdance_amd.ops import untile_weights
+    if set2 is not None and 0 < m_split < m:
+        o = lambda t, e: None if t is None else _off(t, e)  # noqa: E731
+        ff_block(x, out, m=m_split, c=c, w1=w1, s1=s1, s0=s0, w2=w2, b2=b2, ln_eps=ln_eps, x_lo=x_lo, out_lo=out_lo, attn=attn, wo=wo, bo=bo)
+        e = m_split * c
+        ff_block(_off(x, e), _off(out, e), m=m - m_split, c=c, w1=set2["w1"], s1=set2["s1"], s0=set2["s0"], w2=set2["w2"],
+                 b2=set2["b2"], ln_eps=ln_eps, x_lo=o(x_lo, e), out_lo=o(out_lo, e), attn=o(attn, e), wo=set2.get("wo"), bo=set2.get("bo"))
+        return out
+    t = _mem(x, (m, c), (c, 1)).float()
+    if x_lo is not None:
+        t = t + _mem(x_lo, (m, c), (c, 1)).float()
+    if attn is not None:
+        wo_ = untile_weights(_mem(wo, (c, c), (c, 1))).float()
+        t = t + _mem(attn, (m, c), (c, 1)).float() @ wo_.t() + _mem(bo, (c,), (1,))
+    t16 = t.to(F16).float()   # the fp16 rows the kernel multiplies with (and takes the LayerNorm statistics of)
+    mu = t16.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(t16.var(-1, unbiased=False, keepdim=True) + ln_eps)
+    w1_ = untile_weights(_mem(w1, (8 * c, c), (c, 1))).float()
+    y = rstd * (t16 @ w1_.t() - mu * _mem(s1, (8 * c,), (1,))) + _mem(s0, (8 * c,), (1,))
+    y = y.reshape(m, 8 * c // 32, 2, 16)
+    h = (y[:, :, 0, :] * F.gelu(y[:, :, 1, :])).reshape(m, 4 * c).to(F16).float()
+    w2_ = untile_weights(_mem(w2, (c, 4 * c), (4 * c, 1))).float()
+    v = h @ w2_.t() + _mem(b2, (c,), (1,)) + t
+    o = _mem(out, (m, c), (c, 1))
+    o.copy_(v)
+    if out_lo is not None:
+        _mem(out_lo, (m, c), (c, 1)).copy_(v - o.float())
+    return out
+
+
 def _to_e4m3(t):
     """fp32 -> OCP e4m3 bytes (saturating, as the hardware conversion)"""
     return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
@@ -386,7 +423,7 @@ class _Event:
 def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
-    for name in ("igemm", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
+    for name in ("igemm", "ff_block", "ff_block_supported", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
                  "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "gather_frames", "cfg_scatter_add", "window_mean", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -62,6 +62,15 @@ for (bb, hw, c0, c1), parts in itertools.product(((2, 4096, 320, 0), (3, 4096, 6
     seen.add(lib.md_groupnorm(C.byref(g), None))
     lib.md_groupnorm_wants_partials(bb, hw, c0 + c1, 32)
     lib.md_groupnorm_workspace_bytes(bb, hw, 32)
+f = _lib.FfBlockParams()
+for (m, c), head, dual, bm in itertools.product(((8192, 320), (12288, 320), (2048, 640), (65536, 320), (192, 1280), (100, 320)), (0, 1), (0, 1), (0, 32, 64, 128, 7)):
+    f.x = f.x_lo = f.out = f.out_lo = f.w1 = f.s1 = f.s0 = f.w2 = f.b2 = ptr
+    f.attn = f.wo = f.bo = ptr if head else 0
+    f.w1_2 = f.s1_2 = f.s0_2 = f.w2_2 = f.b2_2 = ptr if dual else 0
+    f.wo_2 = f.bo_2 = ptr if (dual and head) else 0
+    f.m, f.c, f.ln_eps, f.m_split, f.force_bm = m, c, 1e-5, (m // 3 // 128 * 128 if dual else 0), bm
+    seen.add(lib.md_ff_block(C.byref(f), None))
+    lib.md_ff_block_supported(m, c)
 seen.add(lib.md_layernorm(ptr, ptr, ptr, ptr, 77, 320, 1e-5, None))
 seen.add(lib.md_softmax_rows(ptr, 4096, ptr, 4096, 8, 4096, 0.1, None))
 seen.add(lib.md_add_f16(ptr, ptr, ptr, 4096, 1024, None))
@@ -89,7 +98,7 @@ def test_host_side_of_the_c_abi_is_clean_under_address_sanitizer(tmp_path):
                        timeout=800)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
-    assert "statuses" in r.stdout and " 8" in r.stdout.splitlines()[-1]      # ABI version 8
+    assert "statuses" in r.stdout and " 9" in r.stdout.splitlines()[-1]      # ABI version 9
     # validation outcomes only: bad argument / unsupported / workspace / no-device -- never MD_OK without a GPU
     st = eval(r.stdout.splitlines()[-1].split("statuses", 1)[1].rsplit("]", 1)[0] + "]")
     assert set(st) <= {-1, -2, -3, -4} and -4 in st, st

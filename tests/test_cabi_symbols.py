@@ -35,7 +35,7 @@ def test_header_symbols_are_exported_and_bound(lib_path):
     # the Python binding covers the same set (a symbol added to the header must be bound, and vice versa)
     assert sorted(_lib.SIGNATURES) == declared
     loaded = _lib.load()
-    assert loaded.md_version() == 8 and loaded.md_arch() == b"gfx950"
+    assert loaded.md_version() == 9 and loaded.md_arch() == b"gfx950"
 
 
 def test_param_structs_match_header_layout():
@@ -43,7 +43,7 @@ def test_param_structs_match_header_layout():
     from magicdance_amd import _lib
     src = open(HEADER).read()
     for cname, cls in (("md_igemm_params", _lib.IgemmParams), ("md_attention_params", _lib.AttentionParams),
-                       ("md_groupnorm_params", _lib.GroupNormParams)):
+                       ("md_groupnorm_params", _lib.GroupNormParams), ("md_ff_block_params", _lib.FfBlockParams)):
         body = re.search(r"typedef struct \{([^{}]*)\} " + cname + ";", src).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -66,6 +66,9 @@ def test_launchers_reject_bad_arguments_without_a_gpu(lib_path):
     assert lib.md_igemm(ctypes.byref(p), None) == -1
     a = _lib.AttentionParams()
     assert lib.md_attention(ctypes.byref(a), None) == -1
+    f = _lib.FfBlockParams()
+    assert lib.md_ff_block(ctypes.byref(f), None) == -1
+    assert lib.md_ff_block_supported(8192, 320) == 1 and lib.md_ff_block_supported(8192, 1280) == 0
     assert lib.md_layernorm(None, None, None, None, 4, 320, 1e-5, None) == -1
     assert lib.md_groupnorm_workspace_bytes(2, 4096, 32) > 0
 
@@ -75,7 +78,7 @@ def test_param_structs_match_header_offsets(tmp_path):
     parameter structs with the ctypes mirrors (a type slip -- int32 vs int64, pointer vs int -- would keep the names in order)."""
     from magicdance_amd import _lib
     structs = (("md_igemm_params", _lib.IgemmParams), ("md_attention_params", _lib.AttentionParams),
-               ("md_groupnorm_params", _lib.GroupNormParams))
+               ("md_groupnorm_params", _lib.GroupNormParams), ("md_ff_block_params", _lib.FfBlockParams))
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
     for cname, cls in structs:
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

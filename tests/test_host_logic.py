@@ -431,6 +431,42 @@ def test_fused_step_launch_structure(monkeypatch):
     assert f["igemm"] - m["igemm"] >= 60 and f["groupnorm"] - m["groupnorm"] >= 20 and f["attention"] - m["attention"] >= 5, (m, f)
 
 
+@pytest.mark.parametrize("name", ["small_b1", "small_b2"])
+def test_ff_block_tail_host_logic_matches_reference_golden(monkeypatch, name):
+    """engine.ff_tail (md_ff_block: attn2.to_out + residual, norm3, GEGLU, feed-forward output + residual as one launch) on the
+    emulated ABI: operand packing, the two-term stream in and out, the second parameter set of the merged pose pass -- against the
+    reference golden, and the launch structure (three md_igemm launches fewer per transformer block that takes it)."""
+    hip_emulator.install(monkeypatch)
+    _no_graph(monkeypatch)
+    from magicdance_amd import ops, engine
+    g = H.load_golden(name)
+    mc = int(g["geo_model_channels"])
+    model = H.build_hip_model(mc, int(g["geo_num_heads"]), seed=int(g["seed"]), device="cpu", image_size=int(g["side"]))
+    inp = H.case_inputs(g)
+    frames = int(g["frames"])
+    counts = {}
+    for n in ("igemm", "ff_block"):
+        def wrap(*a, _o=getattr(ops, n), _n=n, **kw):
+            counts[_n] = counts.get(_n, 0) + 1
+            return _o(*a, **kw)
+        monkeypatch.setattr(ops, n, wrap)
+    res = {}
+    for chans in ((), (mc, 2 * mc, 4 * mc)):
+        monkeypatch.setattr(engine, "_FF_BLOCK", chans)
+        model._fused = None
+        counts.clear()
+        z, _ = model.sample_log(cond=inp["c"], batch_size=frames, ddim=True, ddim_steps=int(g["steps"]), eta=0.0,
+                                unconditional_guidance_scale=7, unconditional_conditioning=inp["uc"], inpaint=None, x_T=inp["x_T"])
+        assert model._fused is not None
+        assert _rel(z.numpy(), g["z"]) <= 2e-2
+        counts.clear()
+        model._fused._launch_sequence()
+        res[chans] = (z, dict(counts))
+    (z0, c0), (z1, c1) = res[()], res[(mc, 2 * mc, 4 * mc)]
+    assert c0.get("ff_block", 0) == 0 and c1["ff_block"] == 16 and c0["igemm"] - c1["igemm"] == 3 * 16, (c0, c1)
+    assert _rel(z1.numpy(), z0.numpy()) <= 5e-3
+
+
 def test_tiled_weight_storage_round_trip_and_layout():
     """ops.tile_weights: the storage form of md_igemm_params.w_tiled.  Round trip, the documented block addressing, and the
     property the engine relies on: a row range that starts at a multiple of 16 is the tiled form of that sub-matrix."""

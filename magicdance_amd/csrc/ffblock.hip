@@ -32,6 +32,12 @@
 
 #include "md_common.h"
 
+#ifndef MD_FF_ABLATE
+#define MD_FF_ABLATE 0   // timing experiments only (tools/ffblock_bench.py): 1 no s1 / s0 DMA, 2 no DMA at all, 4 no MFMAs
+#endif
+
+#define FF_MFMA(a, b, c) ((MD_FF_ABLATE & 4) ? (c) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0))
+
 namespace {
 
 struct FfArgs {
@@ -111,6 +117,12 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   const int ps = set2 ? 1 : 0;
   const int m0 = set2 ? g.m_split + (tile - g.tiles_m1) * BM : tile * BM;
   const int Mlim = set2 ? g.M : min(g.M, g.m_split);
+  // Every workgroup streams the SAME weight bytes.  In lockstep all 32 CUs of an XCD would ask the same one or two L2 channels
+  // for the same 8 KiB at the same time (measured: 13-17 GB/s per CU, a step per microsecond); so workgroup i walks the hidden
+  // chunks (and the k-tiles of the head GEMM) in an order rotated by i / 8 -- block i runs on XCD i % 8, i / 8 counts the
+  // workgroups of one XCD.  The sums are order-independent up to fp32 rounding; the order is a function of the tile index only.
+  const int tloc = set2 ? tile - g.tiles_m1 : tile;   // (tile within its parameter set: one launch == two launches on the row ranges)
+  const int rot_ch = (tloc >> 3) % NCH, rot_kt = (tloc >> 3) % NKC;
 
   // ---- loader role ------------------------------------------------------------------------------------------------------------
   const int r8 = lane >> 3, c8 = lane & 7;
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 
   int tot = 0;   // LDS-DMA instructions this wave has issued (the vmcnt sequence number of the youngest)
   auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, unsigned voff, unsigned soff) {
+    if (MD_FF_ABLATE & 2) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
     ++tot;
   };
@@ -159,14 +172,18 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   auto issue_piece = [&](int p, int slot) {
     char* const dst = ring + slot * PIECE + wv * 1024;
     if (HEAD && p < HEAD_P) {
-      const int t = p / NKC, i = p - t * NKC;
+      int t = p / NKC;
+      const int i = p - t * NKC;
+      t += rot_kt;
+      if (t >= NKC) t -= NKC;
       dma16(rs_wo, dst, voff_kc, (unsigned)((4 * i) * NKC + t) * 2048u);
       return;
     }
     const int pp = p - HEAD_P;
-    const int j = pp / PPC, q = pp - j * PPC;
-    if (q == 0) {   // s1 | s0 of this wave's S columns of chunk j (wave-private, double-buffered by chunk parity)
-      char* const sd = smem + S_OFF + wv * 1024 + (j & 1) * 512;
+    const int jl = pp / PPC, q = pp - jl * PPC;   // position in the stream -> the hidden chunk this workgroup visits there
+    const int j = jl + rot_ch >= NCH ? jl + rot_ch - NCH : jl + rot_ch;
+    if (q == 0 && !(MD_FF_ABLATE & 3)) {   // s1 | s0 of this wave's S columns of the chunk (wave-private, double-buffered by stream parity)
+      char* const sd = smem + S_OFF + wv * 1024 + (jl & 1) * 512;
       const unsigned so = (unsigned)(j * 128 + scol) * 4u;
       dma4(rs_s1, sd, svoff, so);
       dma4(rs_s0, sd + 256, svoff, so);
@@ -180,7 +197,11 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
     }
   };
   // sequence number of the last DMA instruction of piece p (pieces are one instruction per wave; + the s-loads before it)
-  auto seq_of = [&](int p) { return a_cnt + p + 1 + ((!HEAD || p >= HEAD_P) ? 2 * ((p - HEAD_P) / PPC + 1) : 0); };
+  auto seq_of = [&](int p) {
+    if (MD_FF_ABLATE & 2) return a_cnt;
+    if (MD_FF_ABLATE & 1) return a_cnt + p + 1;
+    return a_cnt + p + 1 + ((!HEAD || p >= HEAD_P) ? 2 * ((p - HEAD_P) / PPC + 1) : 0);
+  };
 
   int pi = 0, pf = 0, pc = 0, islot = 0, cslot = 0;   // issued / freed / consumed piece counts, slot of the next issue / consume
   auto issue_avail = [&] {
@@ -236,8 +257,8 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
         const h8 w0 = frag(Wp, fr * 16 + lr, 0), w1 = frag(Wp, fr * 16 + lr, 1);
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
-          acc[(i0 + k) * FPP + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bf[0][j], acc[(i0 + k) * FPP + u][j], 0, 0, 0);
-          acc[(i0 + k) * FPP + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bf[1][j], acc[(i0 + k) * FPP + u][j], 0, 0, 0);
+          acc[(i0 + k) * FPP + u][j] = FF_MFMA(w0, bf[0][j], acc[(i0 + k) * FPP + u][j]);
+          acc[(i0 + k) * FPP + u][j] = FF_MFMA(w1, bf[1][j], acc[(i0 + k) * FPP + u][j]);
         }
       }
     }
@@ -282,7 +303,10 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   if constexpr (HEAD) {
     // t2 = attn Wo^T + bo + x (+ x_lo): K = C over the resident attention tile
 #pragma unroll 1
-    for (int t = 0; t < NKC; ++t) gemm_c_rows(smem + t * BM * 128);
+    for (int t = 0; t < NKC; ++t) {
+      const int tr = t + rot_kt >= NKC ? t + rot_kt - NKC : t + rot_kt;
+      gemm_c_rows(smem + tr * BM * 128);
+    }
     const float* const bo = g.bo[ps];
     float sm[MF], sq[MF];
 #pragma unroll
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 #pragma unroll
         for (int i = 0; i < NF1; ++i)
 #pragma unroll
-          for (int jj = 0; jj < MF; ++jj) S[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][jj], S[i][jj], 0, 0, 0);
+          for (int jj = 0; jj < MF; ++jj) S[i][jj] = FF_MFMA(wf[ks][i], af[ks][jj], S[i][jj]);
       step_end(2);
     }
     // folded LayerNorm + GEGLU on the accumulators -> fp16 h tile [BM][64] (k-tile layout)

@@ -194,7 +194,7 @@ class DDIMSampler_ReferenceOnly(object):
         if c.get("overlap_sampling"):
             # temporal overlap windows (:569-594) inside the step graph (round 4): the entry points' form -- pose model, clean shared
             # reference, shared text, at least one full window of frames; anything else keeps the per-call route
-            one = lambda ts: sum(t.shape[0] for t in ts) // max(1, len(ts)) == 1 or FusedStepRunner._same_rows(torch.cat(ts, 1))  # noqa: E731
+            one = lambda ts: FusedStepRunner._same_rows(ts)  # noqa: E731
             if not (getattr(self.model, "has_pose", True) and c.get("wonoise", True) and uc.get("image_control") is None
                     and c["c_concat"][0].shape[0] >= FusedStepRunner.OV_WIN and one(c["image_control"]) and one(c["c_crossattn"])):
                 return False
@@ -219,8 +219,7 @@ class DDIMSampler_ReferenceOnly(object):
         elif not c.get("wonoise", True):
             bref = b                                      # noisy reference: one bank per frame
         else:
-            ref = torch.cat(c["image_control"], 1)
-            bref = 1 if (ref.shape[0] == 1 or FusedStepRunner._same_rows(ref)) else ref.shape[0]
+            bref = 1 if FusedStepRunner._same_rows(c["image_control"]) else c["image_control"][0].shape[0]
         app = self.model.engines()[0]
         row = sum(n * ch + ch * engine.kv_ld(n) for n, ch in bank_shapes(app.cfg, (hh, ww)))
         return self.ddim_timesteps.shape[0] * bref * row * (1 if engine.ATTN_FP8 else 2)
@@ -287,9 +286,36 @@ class FusedStepRunner:
         self.tkey = None
         self.pose_stream = torch.cuda.Stream(device=model.device)
 
+    # Facts about the CONTENT of a conditioning tensor (are all its rows equal? is it the tensor the caches were built from?) cost a
+    # device -> host synchronisation when computed.  They are memoised on the IDENTITY of the tensor object(s) -- (id, version counter,
+    # address, shape) with a strong reference held, so an id cannot be recycled -- and the entry points / the bench pass the same
+    # objects for every batch of a sequence: after the first batch no call on this route blocks on the device.
+    _FACTS = {}
+
     @staticmethod
-    def _same_rows(t):
-        return t.shape[0] == 1 or bool((t[1:] == t[:1]).all().item())
+    def _ident(ts):
+        ts = ts if isinstance(ts, (list, tuple)) else [ts]
+        return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape), t.dtype) for t in ts)
+
+    @classmethod
+    def _memo(cls, ts, name, fn):
+        key = (name,) + cls._ident(ts)
+        hit = cls._FACTS.get(key)
+        if hit is not None:
+            return hit[0]
+        if len(cls._FACTS) > 256:
+            cls._FACTS.clear()
+        val = fn()
+        cls._FACTS[key] = (val, list(ts) if isinstance(ts, (list, tuple)) else [ts])   # (keeps the tensors alive: ids stay unique)
+        return val
+
+    @classmethod
+    def _same_rows(cls, ts):
+        """every row (dim 0) of cat(ts, 1) equals the first one -- memoised on the identity of ``ts`` (a tensor or a list)"""
+        lst = ts if isinstance(ts, (list, tuple)) else [ts]
+        if all(t.shape[0] == 1 for t in lst):
+            return True
+        return cls._memo(ts, "same_rows", lambda: all(bool((t[1:] == t[:1]).all().item()) for t in lst))
 
     def plan_table(self, S, bref, world=1, sharded=None):
         """(rows per block, blocks) of the reference-KV table.  A block = ``per`` consecutive DDIM rows = one contiguous piece
@@ -342,9 +368,9 @@ class FusedStepRunner:
         else:
             if noisy:
                 ref = base = rep(ref, b)      # per-frame noise: one bank per frame
-            elif ref.shape[0] > 1 and self._same_rows(ref):
+            elif ref.shape[0] > 1 and self._same_rows(c["image_control"]):
                 ref = ref[:1]          # every frame shares the reference latent: one appearance pass, bank broadcast
-            if ctx.shape[0] > 1 and self._same_rows(ctx):
+            if ctx.shape[0] > 1 and self._same_rows(c["c_crossattn"]):
                 ctx = ctx[:1]
             ctx_app = ctx if ctx.shape[0] in (1, ref.shape[0]) else ctx[:ref.shape[0]]
             ctx_unet = ctx if ctx.shape[0] == 1 else torch.cat([ctx, ctx], 0)
@@ -364,10 +390,17 @@ class FusedStepRunner:
         if ctx_app.shape[0] > 1:
             ctx_app = ctx_app.repeat(per_pass, 1, 1)
         # the context K/V caches are keyed on the tensor passed in; keep stable tensors across calls
-        ckey = torch.cat([ctx_unet.reshape(-1), ctx_app.reshape(-1)[:1]])
-        if getattr(self, "_ctx_src", None) is None or not (self._ctx_src.shape == ckey.shape and torch.equal(self._ctx_src, ckey)
-                                                          and self._ctx_app.shape == ctx_app.shape):
-            self._ctx_src = ckey.clone()
+        # (identity first: the same conditioning objects as last time -> nothing to compare, no synchronisation; fresh objects ->
+        # one content comparison, and only a different content rebuilds the K / V caches)
+        ident = (self._ident(c["c_crossattn"]), self._ident(uc["c_crossattn"]) if balance else None, balance, tuple(ctx_app.shape))
+        ckey = None
+        same = getattr(self, "_ctx_ident", None) == ident
+        if not same and getattr(self, "_ctx_src", None) is not None and self._ctx_app.shape == ctx_app.shape:
+            ckey = torch.cat([ctx_unet.reshape(-1), ctx_app.reshape(-1)[:1]])
+            same = self._ctx_src.shape == ckey.shape and torch.equal(self._ctx_src, ckey)
+        self._ctx_ident, self._ctx_keep = ident, (list(c["c_crossattn"]), list(uc["c_crossattn"]) if balance else None)
+        if not same:
+            self._ctx_src = (torch.cat([ctx_unet.reshape(-1), ctx_app.reshape(-1)[:1]]) if ckey is None else ckey).clone()
             self._ctx_app, self._ctx_unet = ctx_app.contiguous().clone(), ctx_unet.contiguous().clone()
             self._ctx_pose = (self._ctx_unet if balance else (ctx if ctx.shape[0] in (1, b) else ctx[:b])).contiguous().clone()
         self.kv_app = app.context_kv(self._ctx_app)

@@ -111,6 +111,12 @@ def test_entry_point_cli_and_preprocessing(tmp_path):
     assert tuple(t.shape) == (3, 512, 512) and 0.0 <= float(t.min()) and float(t.max()) <= 1.0
     n = entry._load_square_512(p, normalize=True)
     assert abs(float(n.mean()) - (float(t.mean()) - 0.5) / 0.5) < 1e-5
+    # without --use_fp16 the reference samples in fp32 (test_any_image_pose.py:237): this build has no fp32-class arithmetic and
+    # refuses, before touching a device, instead of answering in fp16
+    b = entry.build_parser().parse_args([v for v in argv if v != "--use_fp16"])
+    assert not b.use_fp16
+    with pytest.raises(ValueError, match="--use_fp16 is absent"):
+        entry.run(b)
 
 
 @pytest.mark.parametrize("name", ["vae_small", "vae_full16"])

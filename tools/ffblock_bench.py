@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-from magicdance_amd import ops  # noqa: E402
+from magicdance_amd import ops, _lib  # noqa: E402
+if os.environ.get("MD_HIP_LIB"):   # an experiment build of the library (ablation variants of ffblock.hip)
+    _lib.LIB_PATH = os.environ["MD_HIP_LIB"]
 import test_gpu_ffblock as T  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -161,7 +161,8 @@ class FrozenCLIPEmbedder(nn.Module):
         if layer == "hidden":
             assert layer_idx is not None and 0 <= abs(layer_idx) <= 12
         self._empty = None          # cached embedding of the empty prompt, [1, max_length, hidden]
-        self._engine = None         # ClipTextEngine of the current weights (GPU only; dropped whenever the weights change)
+        self._engine = None         # ClipTextEngine of the current weights (GPU only; rebuilt whenever the weights change; False:
+        self._engine_fp = None      # this geometry is not served by the kernels -> transformers computes it)
         if freeze:
             self.freeze()
 
@@ -192,10 +193,19 @@ class FrozenCLIPEmbedder(nn.Module):
     @torch.no_grad()
     def _encode_ids(self, ids):
         dev = next(self.transformer.parameters()).device
-        if dev.type == "cuda" and self.layer == "last":   # the HIP kernels (no torch arithmetic on the GPU)
-            if self._engine is None:
-                self._engine = ClipTextEngine(self.transformer, dev)
-            return self._engine(ids)
+        if dev.type == "cuda" and self.layer == "last" and self._engine is not False:   # the HIP kernels
+            # the packed fp16 weights belong to ONE state of the parameters: (address, version counter) of every tensor -- an
+            # in-place edit or a load_state_dict on the inner module (neither passes this wrapper's hooks) rebuilds the engine
+            fp = tuple((p.data_ptr(), p._version) for p in self.transformer.parameters())
+            if self._engine is None or self._engine_fp != fp:
+                try:
+                    self._engine, self._engine_fp = ClipTextEngine(self.transformer, dev), fp
+                except NotImplementedError:
+                    # a text tower this library's kernels do not serve (activation other than quick_gelu, head size not 32 / 64 / 128):
+                    # the stock transformers module computes it -- the reference's own arithmetic for this (once-per-sequence) row
+                    self._engine = False
+            if self._engine is not False:
+                return self._engine(ids)
         out = self.transformer(input_ids=ids.to(dev), output_hidden_states=self.layer == "hidden")
         if self.layer == "last":
             return out.last_hidden_state

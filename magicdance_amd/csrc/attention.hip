@@ -1321,6 +1321,12 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
                      2.0 * p->batch * p->heads * p->d * (2.0 * p->nq + 2.0 * nkv), tag);
   // 128-row query blocks (QF 2) halve the K/V traffic per MFMA but need >= ~2 workgroups per CU to hide the per-tile
   // latency chain; below that 64-row blocks win (measured: d=80 72->49 us, d=40 B=1 104->94 us, d=40 B=2 unchanged)
+  {  // the LDS-DMA kernels address each K / V^T operand with 32-bit byte offsets (fp16: 2 bytes per element, e4m3: 1)
+    const long long es = p->kv_fp8 ? 1 : 2;
+    if ((long long)p->n0 * p->ld_k0 * es >= (1LL << 31) || (long long)p->heads * p->d * p->ld_vt0 * es >= (1LL << 31) ||
+        (p->k1 && ((long long)p->n1 * p->ld_k1 * es >= (1LL << 31) || (long long)p->heads * p->d * p->ld_vt1 * es >= (1LL << 31))))
+      return MD_ERR_UNSUPPORTED;
+  }
   if (p->kv_fp8) {
     // e4m3 K / V^T: byte tensors, 16-byte aligned rows (the DMA moves 16-byte chunks)
     if ((p->ld_k0 & 15) || (p->ld_vt0 & 15) || (p->k1 && ((p->ld_k1 & 15) || (p->ld_vt1 & 15)))) return MD_ERR_BAD_ARG;
@@ -1345,10 +1351,6 @@ extern "C" int md_attention(const md_attention_params* p, void* stream) {
   // 128-row query blocks (QF 2) halve the K/V traffic per MFMA but need >= ~2 workgroups per CU to hide the per-tile latency chain
   const long long wg128 = (long long)((p->nq + 127) / 128) * p->heads * p->batch;
   const int qf = wg128 >= 512 ? 2 : 1;
-  // the LDS-DMA kernels address each K / V^T operand with 32-bit byte offsets
-  if ((long long)p->n0 * p->ld_k0 * 2 >= (1LL << 31) || (long long)p->heads * p->d * p->ld_vt0 * 2 >= (1LL << 31) ||
-      (p->k1 && ((long long)p->n1 * p->ld_k1 * 2 >= (1LL << 31) || (long long)p->heads * p->d * p->ld_vt1 * 2 >= (1LL << 31))))
-    return MD_ERR_UNSUPPORTED;
   const bool is_cross = p->n0 != p->nq;
   // v3 where it measured faster than v2 (profiles/round2_attention_microbench.txt): d = 40 (self / bank attention at 64^2,
   // 1.17-1.27x), d = 80 with 64-row query blocks (1.3x); the 77-key cross attention, d = 80 with 128-row blocks (252 VGPRs) and

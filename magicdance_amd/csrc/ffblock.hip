@@ -29,6 +29,7 @@
 // Parity: per-kernel tests vs fp32 torch in tests/test_gpu_ffblock.py; the unfused md_igemm pair stays the reference form.
 #include <cstdio>
 #include <type_traits>
+#include <utility>
 
 #include "md_common.h"
 
@@ -58,32 +59,45 @@ struct FfArgs {
   const float* bo[2];
 };
 
-// s_waitcnt vmcnt(n) lgkmcnt(0) [; s_barrier] with a run-time (wave-uniform) n: the count is an immediate.  A smaller count than
-// asked for is merely stricter.
-template <bool BARRIER>
-__device__ __forceinline__ void cnt_wait(int n) {
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant in the body
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+// own LDS-DMA instructions older than the W youngest have landed; LDS reads / writes of this wave are done; then the barrier
+template <int W>
+__device__ __forceinline__ void wait_barrier() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  n = n < 0 ? 0 : n;
-#define MD_FW(k)                                                                          \
-  case k:                                                                                 \
-    if (BARRIER)                                                                          \
-      asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
-    else                                                                                  \
-      asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory");                    \
-    break;
-  switch (n) {
-    MD_FW(0) MD_FW(1) MD_FW(2) MD_FW(3) MD_FW(4) MD_FW(5) MD_FW(6) MD_FW(7) MD_FW(8) MD_FW(9)
-    MD_FW(10) MD_FW(11) MD_FW(12) MD_FW(13) MD_FW(14) MD_FW(15) MD_FW(16) MD_FW(17) MD_FW(18) MD_FW(19)
-    MD_FW(20) MD_FW(21) MD_FW(22) MD_FW(23) MD_FW(24) MD_FW(25) MD_FW(26) MD_FW(27) MD_FW(28) MD_FW(29)
-    default:
-      if (BARRIER)
-        asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)" ::: "memory");
-  }
-#undef MD_FW
+  static_assert(W >= 0 && W < 60, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W) : "memory");
 #endif
 }
+
+// The weight stream of one workgroup, piece by piece (8 KiB = 64 weight rows x one 64-deep k-tile), and the steps that consume it.
+//   head (optional): NKC k-tiles of Wo, each NKC pieces, consumed two pieces per step ((NKC + 1) / 2 steps per k-tile)
+//   per hidden chunk: NKC k-tiles of the projection x 2 pieces (one step each), then NKC pieces of W2 (two per step)
+// A step refills the slots its predecessor freed with the pieces R positions further down the stream, so everything -- piece type,
+// ring slot, and the number of this wave's DMA instructions that may still be in flight at a step's wait -- is a compile-time
+// function of the step (the previous, run-time form of this bookkeeping cost ~125 scalar instructions per wave and step, and the
+// CU's one scalar unit serialised the eight waves: 0.5 us per step, more than the MFMAs).
+template <int NKC>
+struct Sch {
+  static constexpr int PPC = 3 * NKC;
+  static constexpr int NS = NKC + (NKC + 1) / 2;   // steps per chunk
+  static constexpr int HS = (NKC + 1) / 2;         // steps per head k-tile
+  static constexpr int NP_LAST = NKC % 2 ? 1 : 2;  // pieces of the last step of a chunk / of a head k-tile
+  static constexpr int first(int s) { return s < NKC ? 2 * s : 2 * NKC + 2 * (s - NKC); }
+  static constexpr int np(int s) { return s < NKC ? 2 : (PPC - first(s) < 2 ? PPC - first(s) : 2); }
+  static constexpr int hfirst(int s) { return (s / HS) * NKC + 2 * (s % HS); }
+  static constexpr int hnp(int s) { return NKC - 2 * (s % HS) < 2 ? NKC - 2 * (s % HS) : 2; }
+};
 
 template <int C, int WM, int MF, int R, bool HEAD>
 __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
@@ -94,18 +108,19 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   constexpr int NF1 = 8 / WN;              // S fragments per wave: 128 columns / 16 / WN (pairs: a | gate)
   constexpr int FPP = 4 / WN;              // output fragments per 64-row piece per wave
   constexpr int NF2 = NKC * FPP;           // output fragments per wave
-  constexpr int PPC = 3 * NKC;             // pieces per hidden chunk: 2 NKC (projection) + NKC (W2)
+  using S_ = Sch<NKC>;
+  constexpr int PPC = S_::PPC, NS = S_::NS, HS = S_::HS, NPL = S_::NP_LAST;
   constexpr int HEAD_P = HEAD ? NKC * NKC : 0;
-  constexpr int P_TOTAL = HEAD_P + NCH * PPC;
+  constexpr int UNR = PPC % R == 0 ? 1 : 2;   // chunks per unrolled loop body: the ring slot of a piece must not depend on the trip
   constexpr int PIECE = 8192;
   constexpr int A_BYTES = NKC * BM * 128, H_BYTES = BM * 128, S_BYTES = 8 * 1024;
   constexpr int H_OFF = A_BYTES, S_OFF = H_OFF + H_BYTES, RING_OFF = S_OFF + S_BYTES;
   static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "8 waves as WM x WN");
   static_assert(C % 64 == 0 && RING_OFF + R * PIECE <= 160 * 1024, "LDS budget");
   static_assert(WN * BM * 8 <= H_BYTES, "the statistics exchange fits the (not yet used) h tile");
+  static_assert((UNR * PPC) % R == 0 && NCH % UNR == 0 && R >= 5 && R < PPC - 2, "static ring slots");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const ring = smem + RING_OFF;
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -117,11 +132,11 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   const int ps = set2 ? 1 : 0;
   const int m0 = set2 ? g.m_split + (tile - g.tiles_m1) * BM : tile * BM;
   const int Mlim = set2 ? g.M : min(g.M, g.m_split);
-  // Every workgroup streams the SAME weight bytes.  In lockstep all 32 CUs of an XCD would ask the same one or two L2 channels
-  // for the same 8 KiB at the same time (measured: 13-17 GB/s per CU, a step per microsecond); so workgroup i walks the hidden
-  // chunks (and the k-tiles of the head GEMM) in an order rotated by i / 8 -- block i runs on XCD i % 8, i / 8 counts the
-  // workgroups of one XCD.  The sums are order-independent up to fp32 rounding; the order is a function of the tile index only.
-  const int tloc = set2 ? tile - g.tiles_m1 : tile;   // (tile within its parameter set: one launch == two launches on the row ranges)
+  // Every workgroup streams the SAME weight bytes: workgroup i walks the hidden chunks (and the k-tiles of the head GEMM) in an
+  // order rotated by i / 8 (block i runs on XCD i % 8, i / 8 counts the workgroups of one XCD), so that the CUs of an XCD do not
+  // ask for the same lines at the same time.  The sums are order-independent up to fp32 rounding; the order is a function of the
+  // tile index within its parameter set only (one launch == two launches on the two row ranges, bit for bit).
+  const int tloc = set2 ? tile - g.tiles_m1 : tile;
   const int rot_ch = (tloc >> 3) % NCH, rot_kt = (tloc >> 3) % NKC;
 
   // ---- loader role ------------------------------------------------------------------------------------------------------------
@@ -141,16 +156,17 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   const unsigned voff_kh = (unsigned)(wv >> 1) * (unsigned)(NCH * 2048) + in_panel;   // nk = NCH: W2
   const int scol = wn * (128 / WN);                                 // this wave's first S column inside a chunk
   const unsigned svoff = (unsigned)(lane & (NF1 * 16 - 1)) * 4u;    // (WN = 4: the upper half of the wave re-reads; in range)
+  char* const rbase = smem + RING_OFF + wv * 1024;                  // this wave's 1 KiB of ring slot 0
+  char* const sbase = smem + S_OFF + wv * 1024;                     // this wave's s1 | s0 block (2 x 512 B, by chunk parity)
+  const char* const ring = smem + RING_OFF;
 
-  int tot = 0;   // LDS-DMA instructions this wave has issued (the vmcnt sequence number of the youngest)
   auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, unsigned voff, unsigned soff) {
     if (MD_FF_ABLATE & 2) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
-    ++tot;
   };
   auto dma4 = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, unsigned voff, unsigned soff) {
+    if (MD_FF_ABLATE & 2) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
-    ++tot;
   };
 
   // A tile: NKC k-tiles x BM / 8 row pieces, wave wv takes pieces wv, wv + 8, ...
@@ -166,69 +182,62 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
       }
     }
   }
-  const int a_cnt = tot;
 
-  // ---- the piece stream -------------------------------------------------------------------------------------------------------
-  auto issue_piece = [&](int p, int slot) {
-    char* const dst = ring + slot * PIECE + wv * 1024;
-    if (HEAD && p < HEAD_P) {
-      int t = p / NKC;
-      const int i = p - t * NKC;
-      t += rot_kt;
-      if (t >= NKC) t -= NKC;
-      dma16(rs_wo, dst, voff_kc, (unsigned)((4 * i) * NKC + t) * 2048u);
-      return;
-    }
-    const int pp = p - HEAD_P;
-    const int jl = pp / PPC, q = pp - jl * PPC;   // position in the stream -> the hidden chunk this workgroup visits there
-    const int j = jl + rot_ch >= NCH ? jl + rot_ch - NCH : jl + rot_ch;
-    if (q == 0 && !(MD_FF_ABLATE & 3)) {   // s1 | s0 of this wave's S columns of the chunk (wave-private, double-buffered by stream parity)
-      char* const sd = smem + S_OFF + wv * 1024 + (jl & 1) * 512;
-      const unsigned so = (unsigned)(j * 128 + scol) * 4u;
-      dma4(rs_s1, sd, svoff, so);
-      dma4(rs_s0, sd + 256, svoff, so);
-    }
-    if (q < 2 * NKC) {
-      const int t = q >> 1, half = q & 1;
-      dma16(rs_w1, dst, voff_kc, (unsigned)((j * 8 + half * 4) * NKC + t) * 2048u);
+  // ---- the piece stream (static) ----------------------------------------------------------------------------------------------
+  // physical chunk of the current logical chunk and of the next one (rotation), and what the addresses need of them
+  int jr = rot_ch, jr1 = rot_ch + 1 == NCH ? 0 : rot_ch + 1;
+  unsigned w1b0, w1b1, w2b0, w2b1;
+  auto set_bases = [&] {
+    w1b0 = (unsigned)jr * (unsigned)(8 * NKC * 2048);
+    w1b1 = (unsigned)jr1 * (unsigned)(8 * NKC * 2048);
+    w2b0 = (unsigned)jr * 2048u;
+    w2b1 = (unsigned)jr1 * 2048u;
+  };
+  set_bases();
+  int par = 0;   // parity of the current logical chunk: which half of the s1 | s0 block it reads
+  auto issue_s = [&](int jphys, int parity) {   // s1 | s0 of this wave's S columns of a chunk (wave-private)
+    char* const sd = sbase + parity * 512;
+    const unsigned so = (unsigned)(jphys * 128 + scol) * 4u;
+    dma4(rs_s1, sd, svoff, so);
+    dma4(rs_s0, sd + 256, svoff, so);
+  };
+  // the piece at offset OFF (>= 0) from the first piece of body chunk U (logical chunk j, j % UNR == U): chunk j or j + 1
+  auto issue_ff = [&](auto offc, auto uc) {
+    constexpr int off = decltype(offc)::value, u = decltype(uc)::value;
+    constexpr int dj = off / PPC, qi = off % PPC;
+    static_assert(off >= 0 && dj <= 1, "a step reaches at most into the next chunk");
+    constexpr int slot = (HEAD_P + u * PPC + off) % R;
+    char* const dst = rbase + slot * PIECE;
+    if constexpr (qi < 2 * NKC) {
+      constexpr int t = qi >> 1, half = qi & 1;
+      dma16(rs_w1, dst, voff_kc, (dj ? w1b1 : w1b0) + (unsigned)(((half * 4) * NKC + t) * 2048));
     } else {
-      const int i = q - 2 * NKC;
-      dma16(rs_w2, dst, voff_kh, (unsigned)((4 * i) * NCH + j) * 2048u);
+      constexpr int i = qi - 2 * NKC;
+      dma16(rs_w2, dst, voff_kh, (dj ? w2b1 : w2b0) + (unsigned)((4 * i) * NCH * 2048));
     }
   };
-  // sequence number of the last DMA instruction of piece p (pieces are one instruction per wave; + the s-loads before it)
-  auto seq_of = [&](int p) {
-    if (MD_FF_ABLATE & 2) return a_cnt;
-    if (MD_FF_ABLATE & 1) return a_cnt + p + 1;
-    return a_cnt + p + 1 + ((!HEAD || p >= HEAD_P) ? 2 * ((p - HEAD_P) / PPC + 1) : 0);
+  // the piece at offset HOFF of the whole stream while the head runs: a head piece, or (HOFF >= HEAD_P) a piece of chunk 0
+  auto issue_head = [&](auto hoffc) {
+    constexpr int hoff = decltype(hoffc)::value;
+    if constexpr (hoff < HEAD_P) {
+      constexpr int t = hoff / NKC, i = hoff % NKC;
+      const int tr = t + rot_kt >= NKC ? t + rot_kt - NKC : t + rot_kt;
+      dma16(rs_wo, rbase + (hoff % R) * PIECE, voff_kc, (unsigned)((4 * i) * NKC + tr) * 2048u);
+    } else {
+      if constexpr (hoff == HEAD_P) issue_s(jr, 0);
+      issue_ff(ic<hoff - HEAD_P>{}, ic<0>{});
+    }
   };
 
-  int pi = 0, pf = 0, pc = 0, islot = 0, cslot = 0;   // issued / freed / consumed piece counts, slot of the next issue / consume
-  auto issue_avail = [&] {
-    while (pi < P_TOTAL && pi < pf + R) {
-      issue_piece(pi, islot);
-      ++pi;
-      islot = islot + 1 == R ? 0 : islot + 1;
-    }
-  };
-  // a step over the next np pieces: they have landed (own DMA counted, then the barrier); every wave is done with the previous
-  // step's pieces -> their slots are refilled
-  auto step_begin = [&](int np) {
-    cnt_wait<true>(tot - seq_of(pc + np - 1));
-    pf = pc;
-    issue_avail();
-  };
-  auto step_end = [&](int np) {
-    pc += np;
-    cslot += np;
-    if (cslot >= R) cslot -= R;
-  };
-  auto slot_ptr = [&](int k) -> const char* {
-    int s = cslot + k;
-    if (s >= R) s -= R;
-    return ring + s * PIECE;
-  };
-  issue_avail();   // fill the ring behind the A tile
+  // prologue: behind the A tile the first R - NPL pieces (as if a step of NPL pieces had just run)
+  if constexpr (!HEAD) issue_s(jr, 0);
+  static_for<R - NPL>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    if constexpr (HEAD)
+      issue_head(ic<p>{});
+    else
+      issue_ff(ic<p>{}, ic<0>{});
+  });
 
   // ---- fragment reads -----------------------------------------------------------------------------------------------------------
   // operand fragment (16 rows x 32 k) of a [rows][64] k-tile image: lane (lr, lg) holds row lr, k = ks 32 + lg 8 .. + 7
@@ -243,50 +252,21 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[f][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // acc += B-operand fragments bf (this wave's rows, K = 64) x the 64-row weight pieces k = 0 .. np - 1 of the current step, which
-  // hold output fragments 4 (i0 + k) .. + 3
-  auto mma_pieces = [&](const h8 (&bf)[2][MF], int np, auto i0c) {
-    constexpr int i0 = decltype(i0c)::value;
+  // acc += B-operand fragments bf (this wave's rows, K = 64) x the weight piece in ring slot SLOT, which holds output fragments
+  // 4 I .. 4 I + 3
+  auto mma_piece = [&](const h8 (&bf)[2][MF], auto slotc, auto ic_) {
+    constexpr int slot = decltype(slotc)::value, i = decltype(ic_)::value;
+    const char* const Wp = ring + slot * PIECE;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k >= np) break;
-      const char* const Wp = slot_ptr(k);
+    for (int u = 0; u < FPP; ++u) {
+      const int fr = WN == 2 ? 2 * u + wn : wn;
+      const h8 w0 = frag(Wp, fr * 16 + lr, 0), w1 = frag(Wp, fr * 16 + lr, 1);
 #pragma unroll
-      for (int u = 0; u < FPP; ++u) {
-        const int fr = WN == 2 ? 2 * u + wn : wn;
-        const h8 w0 = frag(Wp, fr * 16 + lr, 0), w1 = frag(Wp, fr * 16 + lr, 1);
-#pragma unroll
-        for (int j = 0; j < MF; ++j) {
-          acc[(i0 + k) * FPP + u][j] = FF_MFMA(w0, bf[0][j], acc[(i0 + k) * FPP + u][j]);
-          acc[(i0 + k) * FPP + u][j] = FF_MFMA(w1, bf[1][j], acc[(i0 + k) * FPP + u][j]);
-        }
+      for (int j = 0; j < MF; ++j) {
+        acc[i * FPP + u][j] = FF_MFMA(w0, bf[0][j], acc[i * FPP + u][j]);
+        acc[i * FPP + u][j] = FF_MFMA(w1, bf[1][j], acc[i * FPP + u][j]);
       }
     }
-  };
-  // the NKC pieces of one [C][64] weight k-tile, two per step
-  auto gemm_c_rows = [&](const char* bbase) {
-    h8 bf[2][MF];
-    bool have = false;
-    auto one = [&](auto i0c) {
-      constexpr int i0 = decltype(i0c)::value;
-      constexpr int np = NKC - i0 < 2 ? NKC - i0 : 2;
-      step_begin(np);
-      if (!have) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int j = 0; j < MF; ++j) bf[ks][j] = frag(bbase, arow + 16 * j, ks);
-        have = true;
-      }
-      mma_pieces(bf, np, i0c);
-      step_end(np);
-    };
-    one(std::integral_constant<int, 0>{});
-    if constexpr (NKC > 2) one(std::integral_constant<int, 2>{});
-    if constexpr (NKC > 4) one(std::integral_constant<int, 4>{});
-    if constexpr (NKC > 6) one(std::integral_constant<int, 6>{});
-    if constexpr (NKC > 8) one(std::integral_constant<int, 8>{});
-    static_assert(NKC <= 10, "piece steps");
   };
   // output column of this lane's 4 values of output fragment f
   auto out_col = [&](int f) {
@@ -296,17 +276,31 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   };
 
   // ---- the A tile has landed ----------------------------------------------------------------------------------------------------
-  cnt_wait<true>(tot - a_cnt);
+  wait_barrier<R - NPL + (HEAD ? 0 : 2)>();
   float mu[MF], rstd[MF];
   float* const stat = reinterpret_cast<float*>(smem + H_OFF);   // (the h tile is first written after GEMM 1 of chunk 0)
 
   if constexpr (HEAD) {
-    // t2 = attn Wo^T + bo + x (+ x_lo): K = C over the resident attention tile
-#pragma unroll 1
-    for (int t = 0; t < NKC; ++t) {
+    // t2 = attn Wo^T + bo + x (+ x_lo): K = C over the resident attention tile, k-tiles in rotated order
+    static_for<NKC * HS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int np = S_::hnp(s), first = S_::hfirst(s);
+      constexpr int npp = s == 0 ? NPL : S_::hnp(s - 1);
+      constexpr int pfirst = s == 0 ? -NPL : S_::hfirst(s - 1);
+      wait_barrier<R - npp - np>();   // (conservative: the s1 | s0 loads of chunk 0 may sit among the younger instructions)
+      static_for<npp>([&](auto kc) { issue_head(ic<pfirst + decltype(kc)::value + R>{}); });
+      constexpr int t = s / HS, i0 = 2 * (s % HS);
       const int tr = t + rot_kt >= NKC ? t + rot_kt - NKC : t + rot_kt;
-      gemm_c_rows(smem + tr * BM * 128);
-    }
+      h8 bf[2][MF];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) bf[ks][j] = frag(smem + tr * BM * 128, arow + 16 * j, ks);
+      static_for<np>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        mma_piece(bf, ic<(first + k) % R>{}, ic<i0 + k>{});
+      });
+    });
     const float* const bo = g.bo[ps];
     float sm[MF], sq[MF];
 #pragma unroll
@@ -405,64 +399,98 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 
   // ---- the feed-forward: NCH hidden chunks ------------------------------------------------------------------------------------
   const int hp = WN == 2 ? wn : (wn >> 1);           // which of a projection k-tile's two pieces holds this wave's S columns
-  const int rbase = WN == 2 ? 0 : (wn & 1) * 32;     // ... and from which row of it
+  const int rbase_row = WN == 2 ? 0 : (wn & 1) * 32; // ... and from which row of it
   char* const hbuf = smem + H_OFF;
-#pragma unroll 1
-  for (int j = 0; j < NCH; ++j) {
+
+  auto chunk = [&](auto uc) {
+    constexpr int u = decltype(uc)::value;
     f4 S[NF1][MF];
 #pragma unroll
     for (int i = 0; i < NF1; ++i)
 #pragma unroll
       for (int jj = 0; jj < MF; ++jj) S[i][jj] = f4{0.f, 0.f, 0.f, 0.f};
-    // GEMM 1: K = C, one step per k-tile (two pieces: S columns 0..63 | 64..127)
-#pragma unroll 1
-    for (int t = 0; t < NKC; ++t) {
-      step_begin(2);
-      const char* const Wp = slot_ptr(hp);
-      const char* const At = smem + t * BM * 128;
-      h8 af[2][MF], wf[2][NF1];
+    h8 hf[2][MF];
+    static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int np = S_::np(s), first = S_::first(s);
+      constexpr int sp = s == 0 ? NS - 1 : s - 1;
+      constexpr int npp = S_::np(sp);
+      constexpr int pfirst = s == 0 ? -npp : S_::first(sp);   // previous step's first piece, relative to THIS chunk
+      // younger DMA instructions at this wait: the pieces issued since this step's last piece (R - npp - np of them) and, when that
+      // piece was issued before this chunk began, the s1 | s0 pair of the next chunk issued at step 0
+      constexpr int W = R - npp - np + ((s >= 1 && first + np - 1 < R - NPL) ? 2 : 0);
+      wait_barrier<W>();
+      if constexpr (s == 0) issue_s(jr1, par ^ 1);
+      static_for<npp>([&](auto kc) { issue_ff(ic<pfirst + decltype(kc)::value + R>{}, uc); });
+      if constexpr (s < NKC) {
+        // GEMM 1, k-tile s: two pieces (S columns 0..63 | 64..127)
+        constexpr int slot_a = (HEAD_P + u * PPC + first) % R, slot_b = (HEAD_P + u * PPC + first + 1) % R;
+        const char* const Wp = ring + (hp ? slot_b : slot_a) * PIECE;
+        const char* const At = smem + s * BM * 128;
+        h8 af[2][MF], wf[2][NF1];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int jj = 0; jj < MF; ++jj) af[ks][jj] = frag(At, arow + 16 * jj, ks);
+          for (int jj = 0; jj < MF; ++jj) af[ks][jj] = frag(At, arow + 16 * jj, ks);
 #pragma unroll
-        for (int i = 0; i < NF1; ++i) wf[ks][i] = frag(Wp, rbase + i * 16 + lr, ks);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < NF1; ++i)
-#pragma unroll
-          for (int jj = 0; jj < MF; ++jj) S[i][jj] = FF_MFMA(wf[ks][i], af[ks][jj], S[i][jj]);
-      step_end(2);
-    }
-    // folded LayerNorm + GEGLU on the accumulators -> fp16 h tile [BM][64] (k-tile layout)
-    {
-      const char* const sb = smem + S_OFF + wv * 1024 + (j & 1) * 512;
-#pragma unroll
-      for (int pr = 0; pr < NF1 / 2; ++pr) {
-        const f4 s1a = *reinterpret_cast<const f4*>(sb + ((2 * pr) * 16 + lg * 4) * 4);
-        const f4 s1g = *reinterpret_cast<const f4*>(sb + ((2 * pr + 1) * 16 + lg * 4) * 4);
-        const f4 s0a = *reinterpret_cast<const f4*>(sb + 256 + ((2 * pr) * 16 + lg * 4) * 4);
-        const f4 s0g = *reinterpret_cast<const f4*>(sb + 256 + ((2 * pr + 1) * 16 + lg * 4) * 4);
-        const int col = wn * (64 / WN) + pr * 16 + lg * 4;   // hidden column inside the chunk
-#pragma unroll
-        for (int jj = 0; jj < MF; ++jj) {
-          const int row = arow + 16 * jj;
-          h4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float va = rstd[jj] * (S[2 * pr][jj][e] - mu[jj] * s1a[e]) + s0a[e];
-            const float vg = rstd[jj] * (S[2 * pr + 1][jj][e] - mu[jj] * s1g[e]) + s0g[e];
-            hv[e] = (half_t)(va * md::gelu_erf_f(vg));
-          }
-          *reinterpret_cast<h4*>(hbuf + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = hv;
+          for (int i = 0; i < NF1; ++i) wf[ks][i] = frag(Wp, rbase_row + i * 16 + lr, ks);
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < NF1; ++i)
+#pragma unroll
+            for (int jj = 0; jj < MF; ++jj) S[i][jj] = FF_MFMA(wf[ks][i], af[ks][jj], S[i][jj]);
+        if constexpr (s == NKC - 1) {
+          // folded LayerNorm + GEGLU on the accumulators -> fp16 h tile [BM][64] (k-tile layout)
+          const char* const sb = sbase + par * 512;
+#pragma unroll
+          for (int pr = 0; pr < NF1 / 2; ++pr) {
+            const f4 s1a = *reinterpret_cast<const f4*>(sb + ((2 * pr) * 16 + lg * 4) * 4);
+            const f4 s1g = *reinterpret_cast<const f4*>(sb + ((2 * pr + 1) * 16 + lg * 4) * 4);
+            const f4 s0a = *reinterpret_cast<const f4*>(sb + 256 + ((2 * pr) * 16 + lg * 4) * 4);
+            const f4 s0g = *reinterpret_cast<const f4*>(sb + 256 + ((2 * pr + 1) * 16 + lg * 4) * 4);
+            const int col = wn * (64 / WN) + pr * 16 + lg * 4;   // hidden column inside the chunk
+#pragma unroll
+            for (int jj = 0; jj < MF; ++jj) {
+              const int row = arow + 16 * jj;
+              h4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float va = rstd[jj] * (S[2 * pr][jj][e] - mu[jj] * s1a[e]) + s0a[e];
+                const float vg = rstd[jj] * (S[2 * pr + 1][jj][e] - mu[jj] * s1g[e]) + s0g[e];
+                hv[e] = (half_t)(va * md::gelu_erf_f(vg));
+              }
+              *reinterpret_cast<h4*>(hbuf + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = hv;
+            }
+          }
+        }
+      } else {
+        // GEMM 2: K = the chunk's 64 hidden columns; the barrier of its first step published the h tile
+        if constexpr (s == NKC) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < MF; ++jj) hf[ks][jj] = frag(hbuf, arow + 16 * jj, ks);
+        }
+        static_for<np>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          mma_piece(hf, ic<(HEAD_P + u * PPC + first + k) % R>{}, ic<first + k - 2 * NKC>{});
+        });
       }
-    }
-    // GEMM 2: K = the chunk's 64 hidden columns; the first step's barrier publishes the h tile
-    gemm_c_rows(hbuf);
+    });
+    // next chunk
+    jr = jr1;
+    jr1 = jr1 + 1 == NCH ? 0 : jr1 + 1;
+    set_bases();
+    par ^= 1;
+  };
+#pragma unroll 1
+  for (int j = 0; j < NCH; j += UNR) {
+    chunk(ic<0>{});
+    if constexpr (UNR == 2) chunk(ic<1>{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the R - NPL pieces issued past the end of the stream: valid addresses, never read)
 
   // ---- epilogue: + b2 (+ residual) -> hi / lo -------------------------------------------------------------------------------------
   const float* const b2 = g.b2[ps];
@@ -525,11 +553,11 @@ int launch_ff(const FfArgs& g, int tiles, hipStream_t s) {
 template <int C, bool HEAD>
 int launch_ff_bm(const FfArgs& g, int bm, int tiles, hipStream_t s) {
   if constexpr (C == 320) {
-    if (bm == 128) return launch_ff<C, 4, 2, 7, HEAD>(g, tiles, s);
+    if (bm == 128) return launch_ff<C, 4, 2, 6, HEAD>(g, tiles, s);
     if (bm == 64) return launch_ff<C, 4, 1, 10, HEAD>(g, tiles, s);
     if (bm == 32) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
   } else {
-    if (bm == 64) return launch_ff<C, 4, 1, 8, HEAD>(g, tiles, s);
+    if (bm == 64) return launch_ff<C, 4, 1, 6, HEAD>(g, tiles, s);
     if (bm == 32) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
   }
   return MD_ERR_UNSUPPORTED;
@@ -558,14 +586,22 @@ extern "C" int md_ff_block(const md_ff_block_params* p, void* stream) {
       return MD_ERR_BAD_ARG;
   }
   const bool head = p->attn != nullptr;
-  // rows per workgroup: the largest tile that still gives every CU a workgroup (a workgroup streams ALL the block's weights
-  // through its LDS, so fewer, taller tiles move fewer L2 -> LDS bytes; a grid below the CU count leaves CUs idle)
+  // rows per workgroup.  A workgroup streams ALL the block's weights through its LDS whatever its height, and one workgroup (8 waves,
+  // up to 160 KiB of LDS) owns a CU: the launch costs rounds x t(bm) with rounds = ceil(tiles / 256 CUs) and t = the time of one
+  // workgroup, measured on an MI355X (profiles/round5_ffblock_bench.txt: 50 / 72 / 100 us at 32 / 64 / 128 rows for c = 320)
   int bm = p->force_bm;
   if (bm == 0) {
-    if (p->c == 320)
-      bm = p->m >= 128 * 384 ? 128 : 64;
-    else
-      bm = 64;
+    const int cand[3] = {32, 64, 128};
+    const double t320[3] = {50.0, 72.0, 100.0}, t640[3] = {130.0, 193.0, 1e30};
+    double best = 1e30;
+    for (int i = 0; i < 3; ++i) {
+      const long long tl = ((long long)p->m + cand[i] - 1) / cand[i];
+      const double cost = (double)((tl + 255) / 256) * (p->c == 320 ? t320[i] : t640[i]);
+      if (cost < best) {
+        best = cost;
+        bm = cand[i];
+      }
+    }
   }
   if (bm != 32 && bm != 64 && bm != 128) return MD_ERR_BAD_ARG;
   FfArgs g;

@@ -225,7 +225,16 @@ class DDIMSampler_ReferenceOnly(object):
         return self.ddim_timesteps.shape[0] * bref * row * (1 if engine.ATTN_FP8 else 2)
 
     def _table_fits(self, c, uc, shape):
-        return self._table_bytes(c, uc, shape) <= self.TABLE_BUDGET_BYTES
+        """the table fits the configured budget AND what the device has free right now (an already allocated table of the same size
+        counts as free: it is reused) -- otherwise the per-call route runs instead of an allocation failure"""
+        need = self._table_bytes(c, uc, shape)
+        budget = self.TABLE_BUDGET_BYTES
+        dev = getattr(self.model, "device", None)
+        if dev is not None and dev.type == "cuda" and torch.cuda.is_available():
+            st = getattr(self.model, "_fused", None)
+            held = 0 if st is None or getattr(st, "bank_table", None) is None else st.bank_table.numel() * st.bank_table.element_size()
+            budget = min(budget, int(0.8 * torch.cuda.mem_get_info(dev)[0]) + held)
+        return need <= budget
 
     def _fused_sampling(self, c, img, scale, callback, img_callback, log_every_t, intermediates, uc=None):
         model = self.model
@@ -379,7 +388,9 @@ class FusedStepRunner:
         bref = ref.shape[0]
         self.balance, self.nread, self.n_pose = balance, nread, n_pose
         if has_pose:
-            hint = torch.cat(c["c_concat"], 1)
+            # (a single pose tensor is passed on as the caller's OBJECT: hint_features recognises it by identity + version and skips
+            # the content comparison -- a device -> host synchronisation -- that a fresh torch.cat copy would need)
+            hint = c["c_concat"][0] if len(c["c_concat"]) == 1 else torch.cat(c["c_concat"], 1)
             if balance:
                 hint = torch.cat([rep(torch.cat(uc["c_concat"], 1), b), rep(hint, b)], 0)
         else:

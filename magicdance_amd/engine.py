@@ -124,9 +124,37 @@ def _h(t, device):
 
 
 class TiledWeight(torch.Tensor):
-    """fp16 weight bytes in md_igemm's tiled storage.  The layout travels with the TYPE: row slices (``w[c:3 * c]``), ``.to()`` and
-    ``.clone()`` of a TiledWeight are TiledWeights (torch keeps the subclass through its ops), so a launch can never pass tiled bytes
-    with ``w_tiled = 0`` because a Python attribute got lost on the way."""
+    """fp16 weight bytes in md_igemm's tiled storage.  The layout travels with the TYPE, so a launch can never pass tiled bytes with
+    ``w_tiled = 0`` because a Python attribute got lost on the way -- and only through the operations that PRESERVE
+    the layout: a row slice whose start and length are multiples of 16 (a 16-row panel is the storage unit: the
+    slice starts at the same byte offset as in the row-major form), and copies / moves of the same dtype (clone, detach,
+    contiguous, to / cuda / cpu).  Every other torch operation on a TiledWeight (column slices, ``.t()``, arithmetic, ``.float()``,
+    ``torch.cat`` ...) returns a plain Tensor: its bytes are no longer a tiled matrix and ``is_tiled`` says so."""
+    _KEEP = frozenset(("clone", "detach", "contiguous", "to", "cuda", "cpu", "pin_memory", "requires_grad_", "__getitem__"))
+
+    @staticmethod
+    def _panel_rows(idx, nrows):
+        """is ``idx`` (the argument of w[idx]) a whole-panel row range?"""
+        if isinstance(idx, tuple):
+            if len(idx) != 1:
+                return False
+            idx = idx[0]
+        if not isinstance(idx, slice) or idx.step not in (None, 1):
+            return False
+        start, stop, _ = idx.indices(nrows)
+        return start % 16 == 0 and (stop - start) % 16 == 0 and stop > start
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        name = getattr(func, "__name__", "")
+        keep = name in cls._KEEP
+        if keep and name == "__getitem__":
+            keep = len(args) == 2 and isinstance(args[0], TiledWeight) and args[0].dim() == 2 and cls._panel_rows(args[1], args[0].shape[0])
+        strip = lambda t: (t.as_subclass(torch.Tensor) if isinstance(t, TiledWeight) and not (keep and t.dtype == F16) else t)  # noqa: E731
+        if isinstance(out, (tuple, list)):
+            return type(out)(strip(t) for t in out)
+        return strip(out)
 
 
 def tile_w(w, ksize=1):

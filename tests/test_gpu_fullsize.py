@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 TOL_EPS = 2.6e-3        # one apply_model
 TOL_SEAM = 1e-3         # bank / pose tensors (norm and head slice)
 TOL_GUIDED = 5e-3       # guided eps e_u + 7 (e_c - e_u) on the reference's x_t: CFG 7 combines two evaluations
-TOL_TRAJ = {"c0_b1_s20": 1.8e-3, "c1_b1_s50": 1.6e-3, "c2_b8_s2": 3e-3}   # final latent of the free-running loop
+# final latent of the free-running loop: 1.25 x the values measured on the round-5 tree (profiles/round5_parity_fullsize.txt: 8.51e-4 /
+# 6.28e-4 / 1.47e-3; the arithmetic is deterministic across boxes) -- rounds 2-4 asserted 2x, which let configs[0] drift from 8.4e-4 to
+# 9.7e-4 unnoticed (round-4 review); a change that moves a trajectory by a quarter now fails here and has to be looked at
+TOL_TRAJ = {"c0_b1_s20": 1.07e-3, "c1_b1_s50": 7.9e-4, "c2_b8_s2": 1.85e-3}
 
 _LOG = []
 
@@ -191,7 +194,8 @@ def test_50_step_deviation_against_the_fp16_envelope_small_geometry(dev):
     (model_channels 64, latent 16^2; tests/golden/env16_small_b1_s50.npz): eps pair and x_t after EVERY one of the 50 steps.
     Measured 0.57 - 0.92 of the envelope (profiles/round4_parity_envelope.txt); the end of the trajectory sits AT the envelope --
     another batching of the appearance timesteps (different fp32 summation orders in the split-K layers) moved the last steps to
-    1.02 of it -- so the bound here is the envelope with 25 % of room for that rounding noise, not a claim of being better."""
+    1.02 of it in round 4.  Round 5 (the block tail's residual stream crosses md_ff_block in fp32): 0.64 - 0.90; the bound is the
+    envelope itself with 5 % of room for that summation-order noise."""
     g = H.load_golden("env16_small_b1_s50")
     mc, nh, steps = int(g["geo_model_channels"]), int(g["geo_num_heads"]), int(g["steps"])
     m = H.build_hip_model(mc, nh, seed=0, device=dev, image_size=int(g["side"]))
@@ -211,7 +215,33 @@ def test_50_step_deviation_against_the_fp16_envelope_small_geometry(dev):
     assert worst <= SMALL_ENVELOPE_RATIO, worst
 
 
-SMALL_ENVELOPE_RATIO = 1.25   # at the envelope (measured worst ratio 0.92; 1.02 under another appearance batching)
+def test_50_step_deviation_against_the_fp16_envelope_full_width(dev, model):
+    """configs[1] in full -- 512 x 512, full SD-1.5 width, all 50 steps -- against the reference's own fp16 arithmetic:
+    tests/golden/env16_c1_b1_s50.npz (oracle/make_golden.py ENVELOPE_CASES; hours of CPU autocast, generated in the round-5 build
+    container) holds the unmodified reference's autocast-fp16 trajectory, its fp32 side is golden c1_b1_s50.  HIP-vs-fp32 must stay
+    within the reference's fp16-vs-fp32 deviation after EVERY step."""
+    g = _golden_or_skip("env16_c1_b1_s50")
+    g32 = H.load_golden(str(g["fp32_fixture"]))
+    g = dict(g, eps_c_fp32=g32["eps_c"], eps_u_fp32=g32["eps_u"], x_traj_fp32=g32["x_traj"])
+    steps = int(g["steps"])
+    inp, c, uc = _case(g, dev)
+    x_T, ref = inp["x_T"].to(dev), inp["ref"].to(dev)
+    t = torch.full((1,), int(g["t_probe"]), dtype=torch.long, device=dev)
+    e_c = model.apply_model(x_T, t, c, ref).cpu().numpy()
+    e_u = model.apply_model(x_T, t, c, None, uc=True).cpu().numpy()
+    z, inter = model.sample_log(cond=c, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
+                                unconditional_conditioning=uc, inpaint=None, x_T=x_T, log_every_t=1)
+    traj = torch.stack([x.float().cpu() for x in inter["x_inter"]]).numpy()
+    assert traj.shape == g["x_traj_fp32"].shape
+    rows = _envelope_rows(g, e_c, e_u, traj)
+    worst = max(o / th for _, o, th in rows)
+    for what, ours, theirs in rows[:2] + rows[2::10] + rows[-1:]:
+        _LOG.append(f"envelope configs[1] x 50 steps: {what}: HIP vs fp32 {ours:.3e}   reference fp16 vs fp32 {theirs:.3e}   ratio {ours / theirs:.2f}")
+    _LOG.append(f"envelope configs[1] x 50 steps: worst ratio over eps pair + 50 steps {worst:.2f}")
+    assert worst <= ENVELOPE_SLACK, worst
+
+
+SMALL_ENVELOPE_RATIO = 1.05   # round 5: measured worst ratio 0.90 (round 4: 0.92, and 1.02 under another appearance batching -> its bound was 1.25)
 
 
 def test_configs2_batch8_50steps_frames_match_single_frame_references(dev, model):

@@ -184,7 +184,8 @@ typedef struct {
   /* second parameter set (NULL: one set) */
   const void* wo_2; const float* bo_2; const void* w1_2; const float* s1_2; const float* s0_2; const void* w2_2; const float* b2_2;
   int32_t m_split;
-  int32_t force_bm;        /* 0: auto; 32 / 64 / 128 rows per workgroup (tests / tuning; 128 only for c = 320) */
+  int32_t force_bm;        /* 0: auto; 32 / 64 / 128 rows per workgroup (tests / tuning; 128 only for c = 320), + 1000 x the step-schedule
+                            * variant of that height (0 = the launcher's choice; ffblock.hip launch_ff_bm) */
 } md_ff_block_params;
 int md_ff_block(const md_ff_block_params* p, void* stream);
 /* 1 when md_ff_block serves this (rows, channels) */

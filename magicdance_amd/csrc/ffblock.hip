@@ -87,19 +87,25 @@ __device__ __forceinline__ void wait_barrier() {
 // ring slot, and the number of this wave's DMA instructions that may still be in flight at a step's wait -- is a compile-time
 // function of the step (the previous, run-time form of this bookkeeping cost ~125 scalar instructions per wave and step, and the
 // CU's one scalar unit serialised the eight waves: 0.5 us per step, more than the MFMAs).
-template <int NKC>
+template <int NKC, int KT1, int NP2>
 struct Sch {
+  // KT1 projection k-tiles (2 pieces each) per GEMM-1 step, NP2 pieces of W2 / Wo per GEMM-2 / head step: fewer, fatter steps where
+  // the ring has the slots -- a 32-row workgroup does 4 MFMAs per wave and k-tile, so its time is the per-step barrier + LDS latency
   static constexpr int PPC = 3 * NKC;
-  static constexpr int NS = NKC + (NKC + 1) / 2;   // steps per chunk
-  static constexpr int HS = (NKC + 1) / 2;         // steps per head k-tile
-  static constexpr int NP_LAST = NKC % 2 ? 1 : 2;  // pieces of the last step of a chunk / of a head k-tile
-  static constexpr int first(int s) { return s < NKC ? 2 * s : 2 * NKC + 2 * (s - NKC); }
-  static constexpr int np(int s) { return s < NKC ? 2 : (PPC - first(s) < 2 ? PPC - first(s) : 2); }
-  static constexpr int hfirst(int s) { return (s / HS) * NKC + 2 * (s % HS); }
-  static constexpr int hnp(int s) { return NKC - 2 * (s % HS) < 2 ? NKC - 2 * (s % HS) : 2; }
+  static constexpr int N1 = (NKC + KT1 - 1) / KT1;   // GEMM-1 steps per chunk
+  static constexpr int N2 = (NKC + NP2 - 1) / NP2;   // GEMM-2 steps per chunk = steps per head k-tile
+  static constexpr int NS = N1 + N2;
+  static constexpr int HS = N2;
+  static constexpr int kt0(int s) { return s * KT1; }                                            // first k-tile of GEMM-1 step s
+  static constexpr int nkt(int s) { return NKC - s * KT1 < KT1 ? NKC - s * KT1 : KT1; }          // k-tiles of GEMM-1 step s
+  static constexpr int first(int s) { return s < N1 ? 2 * kt0(s) : 2 * NKC + (s - N1) * NP2; }
+  static constexpr int np(int s) { return s < N1 ? 2 * nkt(s) : (NKC - (s - N1) * NP2 < NP2 ? NKC - (s - N1) * NP2 : NP2); }
+  static constexpr int NP_LAST = NKC - (N2 - 1) * NP2;   // pieces of the last step of a chunk / of a head k-tile
+  static constexpr int hfirst(int s) { return (s / HS) * NKC + (s % HS) * NP2; }
+  static constexpr int hnp(int s) { return NKC - (s % HS) * NP2 < NP2 ? NKC - (s % HS) * NP2 : NP2; }
 };
 
-template <int C, int WM, int MF, int R, bool HEAD>
+template <int C, int WM, int MF, int R, bool HEAD, int KT1 = 1, int NP2 = 2>
 __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WN = 8 / WM, BM = 16 * MF * WM;
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   constexpr int NF1 = 8 / WN;              // S fragments per wave: 128 columns / 16 / WN (pairs: a | gate)
   constexpr int FPP = 4 / WN;              // output fragments per 64-row piece per wave
   constexpr int NF2 = NKC * FPP;           // output fragments per wave
-  using S_ = Sch<NKC>;
-  constexpr int PPC = S_::PPC, NS = S_::NS, HS = S_::HS, NPL = S_::NP_LAST;
+  using S_ = Sch<NKC, KT1, NP2>;
+  constexpr int PPC = S_::PPC, NS = S_::NS, HS = S_::HS, NPL = S_::NP_LAST, N1 = S_::N1;
   constexpr int HEAD_P = HEAD ? NKC * NKC : 0;
   constexpr int UNR = PPC % R == 0 ? 1 : 2;   // chunks per unrolled loop body: the ring slot of a piece must not depend on the trip
   constexpr int PIECE = 8192;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
   static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "8 waves as WM x WN");
   static_assert(C % 64 == 0 && RING_OFF + R * PIECE <= 160 * 1024, "LDS budget");
   static_assert(WN * BM * 8 <= H_BYTES, "the statistics exchange fits the (not yet used) h tile");
-  static_assert((UNR * PPC) % R == 0 && NCH % UNR == 0 && R >= 5 && R < PPC - 2, "static ring slots");
+  static_assert((UNR * PPC) % R == 0 && NCH % UNR == 0 && R >= 5 && R <= PPC, "static ring slots");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
       constexpr int pfirst = s == 0 ? -NPL : S_::hfirst(s - 1);
       wait_barrier<R - npp - np>();   // (conservative: the s1 | s0 loads of chunk 0 may sit among the younger instructions)
       static_for<npp>([&](auto kc) { issue_head(ic<pfirst + decltype(kc)::value + R>{}); });
-      constexpr int t = s / HS, i0 = 2 * (s % HS);
+      constexpr int t = s / HS, i0 = NP2 * (s % HS);
       const int tr = t + rot_kt >= NKC ? t + rot_kt - NKC : t + rot_kt;
       h8 bf[2][MF];
 #pragma unroll
@@ -422,26 +428,29 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
       wait_barrier<W>();
       if constexpr (s == 0) issue_s(jr1, par ^ 1);
       static_for<npp>([&](auto kc) { issue_ff(ic<pfirst + decltype(kc)::value + R>{}, uc); });
-      if constexpr (s < NKC) {
-        // GEMM 1, k-tile s: two pieces (S columns 0..63 | 64..127)
-        constexpr int slot_a = (HEAD_P + u * PPC + first) % R, slot_b = (HEAD_P + u * PPC + first + 1) % R;
-        const char* const Wp = ring + (hp ? slot_b : slot_a) * PIECE;
-        const char* const At = smem + s * BM * 128;
-        h8 af[2][MF], wf[2][NF1];
+      if constexpr (s < N1) {
+        // GEMM 1, k-tiles kt0(s) .. : two pieces each (S columns 0..63 | 64..127)
+        static_for<S_::nkt(s)>([&](auto qc) {
+          constexpr int q = decltype(qc)::value, kt = S_::kt0(s) + q;
+          constexpr int slot_a = (HEAD_P + u * PPC + 2 * kt) % R, slot_b = (HEAD_P + u * PPC + 2 * kt + 1) % R;
+          const char* const Wp = ring + (hp ? slot_b : slot_a) * PIECE;
+          const char* const At = smem + kt * BM * 128;
+          h8 af[2][MF], wf[2][NF1];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-          for (int jj = 0; jj < MF; ++jj) af[ks][jj] = frag(At, arow + 16 * jj, ks);
+            for (int jj = 0; jj < MF; ++jj) af[ks][jj] = frag(At, arow + 16 * jj, ks);
 #pragma unroll
-          for (int i = 0; i < NF1; ++i) wf[ks][i] = frag(Wp, rbase_row + i * 16 + lr, ks);
-        }
+            for (int i = 0; i < NF1; ++i) wf[ks][i] = frag(Wp, rbase_row + i * 16 + lr, ks);
+          }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+          for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < NF1; ++i)
+            for (int i = 0; i < NF1; ++i)
 #pragma unroll
-            for (int jj = 0; jj < MF; ++jj) S[i][jj] = FF_MFMA(wf[ks][i], af[ks][jj], S[i][jj]);
-        if constexpr (s == NKC - 1) {
+              for (int jj = 0; jj < MF; ++jj) S[i][jj] = FF_MFMA(wf[ks][i], af[ks][jj], S[i][jj]);
+        });
+        if constexpr (s == N1 - 1) {
           // folded LayerNorm + GEGLU on the accumulators -> fp16 h tile [BM][64] (k-tile layout)
           const char* const sb = sbase + par * 512;
 #pragma unroll
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
         }
       } else {
         // GEMM 2: K = the chunk's 64 hidden columns; the barrier of its first step published the h tile
-        if constexpr (s == NKC) {
+        if constexpr (s == N1) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(512) void ff_block_kernel(const FfArgs g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int C, int WM, int MF, int R, bool HEAD>
+template <int C, int WM, int MF, int R, bool HEAD, int KT1 = 1, int NP2 = 2>
 int launch_ff(const FfArgs& g, int tiles, hipStream_t s) {
   constexpr int BM = 16 * MF * WM;
   constexpr int lds = (C / 64) * BM * 128 + BM * 128 + 8 * 1024 + R * 8192;
@@ -541,24 +550,31 @@ int launch_ff(const FfArgs& g, int tiles, hipStream_t s) {
   int devi = 0;
   MD_HIP_CHECK(hipGetDevice(&devi));
   if (devi < 0 || devi >= 64 || !attr_set[devi]) {
-    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_block_kernel<C, WM, MF, R, HEAD>),
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_block_kernel<C, WM, MF, R, HEAD, KT1, NP2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (devi >= 0 && devi < 64) attr_set[devi] = true;
   }
-  hipLaunchKernelGGL((ff_block_kernel<C, WM, MF, R, HEAD>), dim3(tiles), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((ff_block_kernel<C, WM, MF, R, HEAD, KT1, NP2>), dim3(tiles), dim3(512), lds, s, g);
   MD_HIP_CHECK(hipGetLastError());
   return MD_OK;
 }
 
+// (rows per workgroup, schedule variant) -> instantiation.  Variant 0 of a height is what the launcher picks; the others exist for
+// tools/ffblock_bench.py (force_bm = rows + 1000 * variant).
 template <int C, bool HEAD>
-int launch_ff_bm(const FfArgs& g, int bm, int tiles, hipStream_t s) {
+int launch_ff_bm(const FfArgs& g, int bm, int variant, int tiles, hipStream_t s) {
   if constexpr (C == 320) {
-    if (bm == 128) return launch_ff<C, 4, 2, 6, HEAD>(g, tiles, s);
-    if (bm == 64) return launch_ff<C, 4, 1, 10, HEAD>(g, tiles, s);
-    if (bm == 32) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
+    if (bm == 128 && variant == 0) return launch_ff<C, 4, 2, 6, HEAD>(g, tiles, s);
+    if (bm == 64 && variant == 0) return launch_ff<C, 4, 1, 10, HEAD, 2, 5>(g, tiles, s);
+    if (bm == 64 && variant == 1) return launch_ff<C, 4, 1, 10, HEAD>(g, tiles, s);
+    if (bm == 64 && variant == 2) return launch_ff<C, 4, 1, 10, HEAD, 2, 3>(g, tiles, s);
+    if (bm == 32 && variant == 0) return launch_ff<C, 2, 1, 10, HEAD, 2, 5>(g, tiles, s);
+    if (bm == 32 && variant == 1) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
+    if (bm == 32 && variant == 2) return launch_ff<C, 2, 1, 15, HEAD, 2, 3>(g, tiles, s);
+    if (bm == 32 && variant == 3) return launch_ff<C, 2, 1, 15, HEAD, 3, 5>(g, tiles, s);
   } else {
-    if (bm == 64) return launch_ff<C, 4, 1, 6, HEAD>(g, tiles, s);
-    if (bm == 32) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
+    if (bm == 64 && variant == 0) return launch_ff<C, 4, 1, 6, HEAD>(g, tiles, s);
+    if (bm == 32 && variant == 0) return launch_ff<C, 2, 1, 10, HEAD>(g, tiles, s);
   }
   return MD_ERR_UNSUPPORTED;
 }
@@ -588,11 +604,13 @@ extern "C" int md_ff_block(const md_ff_block_params* p, void* stream) {
   const bool head = p->attn != nullptr;
   // rows per workgroup.  A workgroup streams ALL the block's weights through its LDS whatever its height, and one workgroup (8 waves,
   // up to 160 KiB of LDS) owns a CU: the launch costs rounds x t(bm) with rounds = ceil(tiles / 256 CUs) and t = the time of one
-  // workgroup, measured on an MI355X (profiles/round5_ffblock_bench.txt: 50 / 72 / 100 us at 32 / 64 / 128 rows for c = 320)
-  int bm = p->force_bm;
+  // workgroup, measured on an MI355X (profiles/round5_ffblock_bench.txt: 47 / 68 / 100 us at 32 / 64 / 128 rows for c = 320)
+  int bm = p->force_bm % 1000;
+  const int variant = p->force_bm / 1000;
+  if (p->force_bm < 0) return MD_ERR_BAD_ARG;
   if (bm == 0) {
     const int cand[3] = {32, 64, 128};
-    const double t320[3] = {50.0, 72.0, 100.0}, t640[3] = {130.0, 193.0, 1e30};
+    const double t320[3] = {47.0, 68.0, 100.0}, t640[3] = {130.0, 193.0, 1e30};
     double best = 1e30;
     for (int i = 0; i < 3; ++i) {
       const long long tl = ((long long)p->m + cand[i] - 1) / cand[i];
@@ -639,6 +657,6 @@ extern "C" int md_ff_block(const md_ff_block_params* p, void* stream) {
   snprintf(tag, sizeof(tag), "ff_block M=%d C=%d bm=%d head=%d dual=%d", p->m, p->c, bm, head ? 1 : 0, dual ? 1 : 0);
   md::ProfScope prof(MD_FAM_IGEMM, s, 2.0 * p->m * (12.0 * C * C + (head ? C * C : 0.0)),
                      (double)p->m * C * 2.0 * (head ? 5.0 : 4.0) + (12.0 + (head ? 1.0 : 0.0)) * C * C * 2.0, tag);
-  if (p->c == 320) return head ? launch_ff_bm<320, true>(g, bm, tiles, s) : launch_ff_bm<320, false>(g, bm, tiles, s);
-  return head ? launch_ff_bm<640, true>(g, bm, tiles, s) : launch_ff_bm<640, false>(g, bm, tiles, s);
+  if (p->c == 320) return head ? launch_ff_bm<320, true>(g, bm, variant, tiles, s) : launch_ff_bm<320, false>(g, bm, variant, tiles, s);
+  return head ? launch_ff_bm<640, true>(g, bm, variant, tiles, s) : launch_ff_bm<640, false>(g, bm, variant, tiles, s);
 }

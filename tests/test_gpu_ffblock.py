@@ -61,6 +61,8 @@ CASES = [
     (320, 200, 64, 1, 0), (320, 72, 128, 0, 0), (320, 1000, 32, 1, 1),       # ragged row counts, single-term stream
     (320, 8192, 0, 1, 1), (320, 12288, 0, 0, 1),                              # the one-frame 64 x 64 level, automatic tile
     (640, 256, 32, 0, 1), (640, 256, 64, 1, 1), (640, 2048, 0, 1, 1), (640, 200, 64, 0, 0),
+    # the other step schedules of a tile height (force_bm = rows + 1000 * variant; variant 0 is what the launcher picks)
+    (320, 320, 1032, 1, 1), (320, 320, 2032, 1, 1), (320, 320, 3032, 0, 1), (320, 320, 1064, 1, 1), (320, 320, 2064, 0, 1),
 ]
 
 

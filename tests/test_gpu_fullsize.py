@@ -6,7 +6,7 @@ c2_b8_s2 = configs[2] geometry).  Three kinds of check per case:
   * the free-running DDIM trajectory from x_T (error including its growth through the recurrence).
 Errors are relative to max|reference tensor|; the per-step curves are written to gpurun_out/parity_fullsize.log (copied to
 profiles/).  fp16 operands bound one eps evaluation at ~1.2e-3 (weights ~0.85e-3, activations ~0.9e-3 in
-quadrature); the asserts sit at <= 2x the measured values."""
+quadrature); single-evaluation asserts sit at <= 2x the measured values, every trajectory / recurrence assert at 1.25x (round 5)."""
 import os
 
 import numpy as np
@@ -262,15 +262,15 @@ def test_configs2_batch8_50steps_frames_match_single_frame_references(dev, model
         r = _rel(z8[k:k + 1], g["z"])
         _LOG.append(f"configs[2] B=8 x {steps} steps: frame {k} of the batch vs the reference's single-frame run: rel {r:.3e} "
                     f"(max-abs {np.abs(z8[k:k + 1] - g['z']).max():.3e}, max|z| {np.abs(g['z']).max():.3e})")
-        assert r <= 1.8e-3, (k, r)     # same bound class as configs[1] (measured there: 8.0e-4)
+        assert r <= 8.5e-4, (k, r)     # 1.25x the round-5 measurement (6.74e-4 / 6.44e-4)
     # alone vs in batch, both on the HIP path
     c1, uc1, x1 = _seq_case(g3, [3], dev)
     z1, _ = model.sample_log(cond=c1, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
                              unconditional_conditioning=uc1, inpaint=None, x_T=x1)
     r = _rel(z1.cpu().numpy(), z8[3:4])
     _LOG.append(f"configs[2]: frame 3 sampled alone vs inside the batch of 8 (HIP vs HIP, {steps} steps): rel {r:.3e}")
-    assert r <= 1.5e-3, r
-    assert _rel(z1.cpu().numpy(), g3["z"]) <= 1.8e-3
+    assert r <= 6.8e-4, r     # measured 5.37e-4 (summation-order noise between the tile choices of B = 1 and B = 8)
+    assert _rel(z1.cpu().numpy(), g3["z"]) <= 8.5e-4
 
 
 def test_small_x_T_recurrence_sensitivity(dev, model):
@@ -303,11 +303,11 @@ def test_small_x_T_recurrence_sensitivity(dev, model):
         curve.append(_rel(got, want))
     _LOG.append(f"x_T / 16: guided eps on the reference x_t per step: max {max(curve):.3e} mean {np.mean(curve):.3e}")
     assert max(curve) <= TOL_GUIDED, max(curve)          # a single evaluation is as accurate as at the standard scale ...
-    assert ab / zmax <= 9e-3, ab / zmax                  # ... the recurrence amplifies it more (measured 4.6e-3, 2x bound)
+    assert ab / zmax <= 5.9e-3, ab / zmax                # ... the recurrence amplifies it more (measured 4.68e-3; 1.25x)
 
 
 # ABSOLUTE tolerance of the realistic-scale case = 2x the measured value (1.31e-2 at max|z| 6.55: profiles/round3_parity_fullsize.txt)
-TOL_ABS_REALISTIC = 2.6e-2
+TOL_ABS_REALISTIC = 1.55e-2   # 1.25x the measured 1.237e-2
 
 
 def test_realistic_latent_scale_absolute_deviation(dev):
@@ -362,7 +362,7 @@ def test_configs4_geometry_768_matches_reference(dev, model96):
     assert xs.shape == g["x_traj"].shape
     rz = _rel(z.cpu().numpy(), g["z"])
     _LOG.append(f"c4_b1_s2 (768x768): latent after {steps} steps rel {rz:.3e}")
-    assert rz <= 3e-3, rz
+    assert rz <= 1.95e-3, rz   # measured 1.54e-3
 
 
 def test_configs4_geometry_768_fp8_attention_bound(dev):
@@ -385,4 +385,4 @@ def test_configs4_geometry_768_fp8_attention_bound(dev):
     finally:
         engine.ATTN_FP8 = False
     _LOG.append(f"c4_b1_s2 (768x768) fp8 attention: eps_cond rel {rc:.3e}  eps_uncond rel {ru:.3e}  latent rel {rz:.3e}")
-    assert rc <= 2e-2 and ru <= 2e-2 and rz <= 3e-2, (rc, ru, rz)
+    assert rc <= 5.2e-3 and ru <= 5.1e-3 and rz <= 7.5e-3, (rc, ru, rz)   # 1.25x the measured 4.13e-3 / 4.04e-3 / 5.97e-3 (rounds 3-4 asserted 2e-2 / 3e-2)

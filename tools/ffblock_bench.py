@@ -65,7 +65,7 @@ for c, b, n in shapes:
     flops_ff, flops_head = 2.0 * m * 12 * c * c, 2.0 * m * c * c
     u_all, u_ff = timed(unfused_all), timed(unfused_ff)
     line = [f"C={c} M={m:6d}: md_igemm x3 {u_all:7.1f} us ({(flops_ff + flops_head) / u_all / 1e6:5.0f} TF)  x2 (no to_out) {u_ff:7.1f} us"]
-    for bm in ((32, 64, 128) if c == 320 else (32, 64)):
+    for bm in ((32, 1032, 2032, 3032, 64, 1064, 2064, 128) if c == 320 else (32, 64)):
         try:
             fh, fn = timed(fused(bm, 1)), timed(fused(bm, 0))
             line.append(f"bm{bm}: head {fh:7.1f} us ({(flops_ff + flops_head) / fh / 1e6:5.0f} TF) ff-only {fn:7.1f} us")

@@ -18,7 +18,7 @@ if [ "${MD_ASAN:-0}" = "1" ]; then
 fi
 mkdir -p "$BUILD"
 pids=()
-for f in igemm igemm_ring ffblock attention norm elementwise runtime; do
+for f in igemm igemm_ring igemm_stream ffblock attention norm elementwise runtime; do
   EXTRA=""
   # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified file); the softmax touches every S^T / O
   # element each tile, and the AGPR form cost ~5 v_accvgpr moves per MFMA

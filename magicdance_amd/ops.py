@@ -114,12 +114,18 @@ def igemm_config_info(cfg):
     info = (C.c_int32 * 8)()
     if _lib.load().md_igemm_config_info(int(cfg), C.byref(info)) != _lib.MD_OK:
         return None
-    return dict(bm=info[0], bn=info[1], kt=info[2], kg=info[3], ring=bool(info[4]), d1=info[5], d9=info[6], wn=info[7])
+    return dict(bm=info[0], bn=info[1], kt=info[2], kg=info[3], ring=bool(info[4]), d1=info[5], d9=info[6], wn=info[7], stat=info[4] == 2)
 
 
 def ring_lds_bytes(cfg, ksize, win):
     """dynamic LDS a ring config needs for a layer (the launcher refuses > 160 KiB): mirrors igemm_ring.hip::ring_lds_bytes"""
     c = igemm_config_info(cfg)
+    if c["stat"]:   # the static form (igemm_stream.hip::stream_lds_bytes): 3x3 only, nine W slots + two A blocks of aj x 32 rows
+        aj = (c["bm"] + 2 * win + 2 + 31) // 32
+        lo, hi = (3, 5) if c["bm"] == 64 else (5, 7)
+        if ksize != 3 or aj > hi:
+            return 1 << 40
+        return 9 * c["bn"] * 128 + 2 * max(aj, lo) * 32 * 128 + 128
     if ksize == 3:
         a_rows = (c["bm"] + 2 * win + 2 + 7) & ~7
         return c["d9"] * c["kg"] * c["kt"] * c["bn"] * 128 + 2 * a_rows * 128 + 128

@@ -9,6 +9,8 @@ pytestmark = pytest.mark.gpu
 
 F16, F32 = torch.float16, torch.float32
 RING_CFGS = list(range(40, 65))
+STAT_CFGS = [65, 66]                      # the static ring form (igemm_stream.hip): 3x3 convs only
+CFGS_3X3 = RING_CFGS + STAT_CFGS
 
 
 @pytest.fixture(scope="module")
@@ -64,7 +66,13 @@ def test_ring_config_table(dev):
         assert c is not None and c["ring"] and c["kg"] in (1, 2) and c["kg"] * c["kt"] <= 4 and 2 <= c["d1"] <= 12 and 2 <= c["d9"] <= 12
         assert ops.ring_lds_bytes(cfg, 1, 1) <= 160 * 1024          # every 1x1 launch fits
         assert ops.ring_lds_bytes(cfg, 3, 8) <= 160 * 1024          # and the 8x8 level's 3x3 convs
-    assert ops.igemm_config_info(RING_CFGS[-1] + 1) is None and not ops.igemm_config_info(15)["ring"]
+    for cfg in STAT_CFGS:
+        c = ops.igemm_config_info(cfg)
+        assert c is not None and c["ring"] and c["stat"] and c["bn"] == 64 and c["d9"] == 9
+        assert ops.ring_lds_bytes(cfg, 3, 8) <= 160 * 1024 and ops.ring_lds_bytes(cfg, 3, 16) <= 160 * 1024
+        assert ops.ring_lds_bytes(cfg, 1, 16) > 160 * 1024           # no 1x1 layers
+    assert ops.ring_lds_bytes(65, 3, 64) > 160 * 1024                # a 130-pixel halo: the 64 x 64 level is not this kernel's
+    assert ops.igemm_config_info(STAT_CFGS[-1] + 1) is None and not ops.igemm_config_info(15)["ring"]
 
 
 CONV_CASES = [
@@ -82,7 +90,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", CFGS_3X3)
 @pytest.mark.parametrize("splitk,tiled", [(1, True), (1, False), (2, True), (3, True)])
 def test_ring_conv(dev, case, cfg, splitk, tiled):
     from magicdance_amd import ops, engine
@@ -115,7 +123,7 @@ def test_ring_conv(dev, case, cfg, splitk, tiled):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (name, cfg, "not deterministic")
 
 
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", CFGS_3X3)
 def test_ring_rejects_what_it_cannot_do(dev, cfg):
     """stride 2, upsample and ragged channel counts belong to the 2-stage kernels"""
     from magicdance_amd import ops, _lib
@@ -196,10 +204,12 @@ PART_CASES = [
 
 
 @pytest.mark.parametrize("case", PART_CASES, ids=[c[0] for c in PART_CASES])
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", CFGS_3X3)
 def test_ring_groupnorm_partials(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cin, h, w, cout, k, b2 = case
+    if cfg in STAT_CFGS and k != 3:
+        pytest.skip("the static ring form serves 3x3 convs")
     x = _rand((b, cin, h, w), 1, dev)
     wt = _rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5)
     wt2 = _rand((cout, cin, k, k), 12, dev, (cin * k * k) ** -0.5)
@@ -225,7 +235,7 @@ def test_ring_groupnorm_partials(dev, case, cfg):
 
 @pytest.mark.parametrize("case", [("c3", 3, 2, 320, 8, 8, 128, 3), ("c3_ragged", 3, 2, 64, 6, 6, 96, 3), ("c1", 6, 4, 320, 16, 16, 320, 1),
                                   ("c3_16", 3, 2, 1280, 16, 16, 160, 3)])
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", CFGS_3X3)
 @pytest.mark.parametrize("splitk", [1, 2])
 def test_ring_second_parameter_set(dev, case, cfg, splitk):
     """w2 / bias2 / batch2 through the ring: one launch == two launches on the two sample ranges, bit for bit (the second set's
@@ -254,7 +264,7 @@ def test_ring_second_parameter_set(dev, case, cfg, splitk):
     assert float((one[:b2].float() - one[b2:b2 + 1].float()).abs().max()) > 0.05
 
 
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", CFGS_3X3)
 def test_ring_matches_two_stage_kernels_under_load(dev, cfg):
     """the step's real small-M shapes with cold weights in rotation and a bandwidth hog on a second stream: repeated launches stay
     bit-identical to the first (a counted wait that is one load short shows up here, not on an idle chip)"""

@@ -41,13 +41,17 @@ def _ring_cfgs():
     first = int(re.search(r"kFirstRingCfg = (\d+)", open(os.path.join(os.path.dirname(RING), "igemm_core.h")).read()).group(1))
     body = src[src.index("const RingCfg kRing[] = {"):]
     body = body[:body.index("};")]
-    rows = re.findall(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},\s*//\s*(\d+)", body)
+    rows = re.findall(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?\},\s*//\s*(\d+)", body)
     out = {}
     for i, r in enumerate(rows):
-        assert int(r[9]) == first + i, "kRing comment ids follow the array order"
-        out[first + i] = tuple(int(v) for v in r[:8]) + (int(r[8] or 0),)
-    # the launcher's switch instantiates exactly the table's rows
-    for cid, (bm, bn, wm, wn, kt, kg, d1, d9, pipe) in out.items():
+        assert int(r[10]) == first + i, "kRing comment ids follow the array order"
+        out[first + i] = tuple(int(v) for v in r[:8]) + (int(r[8] or 0), int(r[9] or 0))
+    # the launcher's switch instantiates exactly the table's rows (the static form, round 5, dispatches on the row itself)
+    assert "c && c->stat) return igemm_stream_launch(g, c->bm, c->bn, s);" in src
+    for cid, (bm, bn, wm, wn, kt, kg, d1, d9, pipe, stat) in out.items():
+        if stat:
+            assert (bm, bn, wm * wn, d9) in ((64, 64, 4, 9), (128, 64, 4, 9)), cid   # what igemm_stream.hip instantiates
+            continue
         assert f"case {cid}: return launch_ring_t<{bm}, {bn}, {wm}, {wn}, {kt}, {kg}, {d1}, {d9}{', true' if pipe else ''}>(g, s);" in src, cid
     return out
 
@@ -62,7 +66,12 @@ def test_tuned_table_entries_are_valid():
     ring = _ring_cfgs()
     for (m, n, k, ks, st, ups, cfg, split, kg, line) in ents:
         if cfg in ring:   # the ring form: stride 1, no upsample, whole channel blocks per split, its own k-groups, LDS fit at 8x8
-            bm, bn, wm, wn, kt, rkg, d1, d9, _pipe = ring[cfg]
+            bm, bn, wm, wn, kt, rkg, d1, d9, _pipe, stat = ring[cfg]
+            if stat:   # the static form: 3x3 convs, nine W slots + two haloed A blocks padded to 32 rows (LDS fit at 8x8 / 16x16)
+                assert ks == 3 and st == 1 and ups == 0 and (k // 9) % 64 == 0 and kg in (0, 1) and 1 <= split <= k // 64 // 9, line
+                aj = max((bm + 2 * 16 + 2 + 31) // 32, 3 if bm == 64 else 5)
+                assert 9 * bn * 128 + 2 * aj * 32 * 128 + 128 <= 160 * 1024, line
+                continue
             assert st == 1 and ups == 0 and ks in (1, 3) and (k // (ks * ks)) % 64 == 0, line
             assert kg in (0, rkg), line
             units = k // 64 // (9 if ks == 3 else 1)

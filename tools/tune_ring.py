@@ -154,7 +154,8 @@ for ln in lines:
     tag = ""
     if cfg >= 40:
         nring += 1
-        tag = f"  [round 4, ring: {base:.1f} -> {us:.1f}us]"
+        tag = (f"  [round 5, static ring: {base:.1f} -> {us:.1f}us]" if ops.igemm_config_info(cfg).get("stat") else
+               f"  [round 4, ring: {base:.1f} -> {us:.1f}us]")
         out_lines.append(f"    {{{M}, {N}, {K}, {ks}, {st}, {up}, {cfg}, {sp}, {kg}}},  // x{count} {us:.1f}us {2.0 * M * N * K / us / 1e6:.0f}TF "
                          f"(B={B} {h}x{w} c={c0}+{c1}){tag}")
     else:

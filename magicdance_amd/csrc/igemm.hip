@@ -749,7 +749,7 @@ extern "C" int md_igemm_config_info(int32_t cfg, int32_t info[8]) {
   info[1] = cfg_of(cfg).bn;
   info[2] = kt;
   info[3] = max_kg(cfg);
-  info[4] = r ? (r->stat ? 2 : 1) : 0;
+  info[4] = r ? 1 + r->stat : 0;
   info[5] = r ? r->d1 : 2;
   info[6] = r ? r->d9 : 2;
   info[7] = r ? r->wn : 0;

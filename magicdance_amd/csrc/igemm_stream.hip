@@ -231,6 +231,190 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_stream_kernel(co
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// The same for 1x1 convs / linear layers (configs 67.., round 5): a ring of R slots, each one k-tile of A ([BM][64]) and of W ([BN][64]);
+// a step = TPS k-tiles; the unrolled loop body covers R k-tiles, so slot and wait count are compile-time again:
+//   step j of a body issues the k-tiles R ahead of the ones step j - 1 consumed (into that step's slots) -> before a step's wait the
+//   wave has issued (R - 2 TPS) k-tiles = (R - 2 TPS) (AJ1 + WJ) instructions after the step's own.
+// K = 1280 linears of the 8x8 / 16x16 levels (20 k-tiles, M = 64 .. 768): the 2-stage kernels pay one L2 / HBM round trip per pipeline
+// stage (vmcnt(0)); here 6 of 8 slots (96 KiB per CU) are in flight across every barrier.  Folded LayerNorm as in the other kernels.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int R, int TPS, bool LN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_stream1_kernel(const IgemmArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  constexpr int TILE_A = BM * 128, TILE_W = BN * 128, SLOT = TILE_A + TILE_W;
+  constexpr int AJ1 = BM / 8 / NW, WJ = BN / 8 / NW, IPT = AJ1 + WJ;
+  constexpr int LDS_TOTAL = R * SLOT;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WTM <= 64 && LDS_TOTAL <= 160 * 1024 && R % TPS == 0 && R >= 2 * TPS, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wv % WAVES_M, wn = wv / WAVES_M;
+
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8g = nwg & 7;
+  const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
+  const int per_group = g.group_m * g.tiles_n;
+  const int grp = logical / per_group, in_grp = logical - grp * per_group;
+  const int first_m = grp * g.group_m;
+  const int gsz = min(g.tiles_m - first_m, g.group_m);
+  const int tile_n = in_grp / gsz, tile_m = first_m + (in_grp - tile_n * gsz);
+  const bool set2 = tile_m >= g.tiles_m1;
+  const int m0 = set2 ? g.m_split + (tile_m - g.tiles_m1) * BM : tile_m * BM;
+  const int Mlim = set2 ? g.M : min(g.M, g.m_split);
+  const int n0 = tile_n * BN;
+  const int kz = blockIdx.z;
+  const int kt_begin = kz * g.tiles_per_split;
+  const int nkt = max(0, min(g.nk, kt_begin + g.tiles_per_split) - kt_begin);
+  const half_t* const gw = set2 ? g.w2 : g.w;
+
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const unsigned gcb = (unsigned)(c8 ^ r8) * 16u;
+  const int mtot = g.batch * g.hin * g.win;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(gw), 0, g.N * g.K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.a0), 0, mtot * g.c0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.a1 ? g.a1 : g.a0), 0, mtot * (g.a1 ? g.c1 : g.c0) * 2, 0x00020000);
+  unsigned w_off[WJ], ra0[AJ1], ra1[AJ1];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) w_off[j] = w_row_offset(min(n0 + (wv + NW * j) * 8 + r8, g.N - 1), g) + gcb;
+#pragma unroll
+  for (int j = 0; j < AJ1; ++j) {
+    const unsigned m = (unsigned)min(m0 + (wv + NW * j) * 8 + r8, Mlim - 1);   // rows past the end: clamped, never stored
+    ra0[j] = m * (unsigned)g.c0 * 2u + gcb;
+    ra1[j] = m * (unsigned)g.c1 * 2u + gcb;
+  }
+  const unsigned wk_stride = g.w_tiled ? 2048u : 128u;
+  char* const dst0 = smem + wv * 1024;
+  const int c0v = g.c0;
+
+  // k-tile ``rel`` of this workgroup (clamped to its last one: loads past the end read valid addresses and are never consumed) -> slot
+  auto issue_tile = [&](int rel, auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    const int kt = kt_begin + min(rel, nkt - 1);
+    const int cc = kt * 64;
+    const bool second = cc >= c0v;
+    const unsigned soff = (unsigned)(second ? cc - c0v : cc) * 2u;
+    char* const d = dst0 + slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < AJ1; ++j) {
+      if (second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (__attribute__((address_space(3))) void*)(d + NW * 1024 * j), 16, ra1[j], soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, (__attribute__((address_space(3))) void*)(d + NW * 1024 * j), 16, ra0[j], soff, 0, 0);
+    }
+    const unsigned ksoff = (unsigned)kt * wk_stride;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(d + TILE_A + NW * 1024 * j), 16, w_off[j], ksoff, 0, 0);
+  };
+
+  f4 acc[NF][MF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float ln_sum[MF], ln_sq[MF];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i) ln_sum[i] = ln_sq[i] = 0.f;
+  }
+
+  auto compute_tile = [&](auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    const char* const At = smem + slot * SLOT;
+    const char* const Wt = At + TILE_A;
+    h8 af[2][MF], wf[2][NF];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int row = wm * WTM + i * 16 + lr;
+        af[ks][i] = *reinterpret_cast<const h8*>(At + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int row = wn * WTN + i * 16 + lr;
+        wf[ks][i] = *reinterpret_cast<const h8*>(Wt + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (LN) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          if (WAVES_N > 1 && (i % WAVES_N) != wn) continue;   // (the n-waves of a wave row share the statistics work: igemm.hip)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const h2v p = {af[ks][i][2 * e], af[ks][i][2 * e + 1]};
+            ln_sum[i] = __builtin_amdgcn_fdot2(p, ones, ln_sum[i], false);
+            ln_sq[i] = __builtin_amdgcn_fdot2(p, p, ln_sq[i], false);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // prologue: k-tiles 0 .. R - TPS - 1 (as if a step of TPS tiles had just run)
+  if (nkt > 0) sfor<R - TPS>([&](auto tc) { issue_tile(decltype(tc)::value, tc); });
+#pragma unroll 1
+  for (int base = 0; base < nkt; base += R) {
+    sfor<R / TPS>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (base + j * TPS < nkt) {   // (uniform: the steps past this workgroup's last k-tile are skipped by every wave)
+        wait_barrier<(R - 2 * TPS) * IPT>();
+        // refill the slots of the previous step with the k-tiles R further on
+        sfor<TPS>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          constexpr int slot = ((j + R / TPS - 1) % (R / TPS)) * TPS + k;
+          issue_tile(base + (j - 1) * TPS + k + R, std::integral_constant<int, slot>{});
+        });
+        sfor<TPS>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if (base + j * TPS + k < nkt) compute_tile(std::integral_constant<int, j * TPS + k>{});
+        });
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const __attribute__((address_space(4))) IgemmArgs* gp = (const __attribute__((address_space(4))) IgemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(gp));
+  const IgemmArgs ge = *gp;
+  igemm_epilogue<BM, BN, WAVES_M, WAVES_N, LN, 1, LDS_TOTAL>(ge, smem, acc, ln_sum, ln_sq, tid, 0, wm, wn, m0, n0, Mlim, kz,
+                                                             set2 ? ge.bias2 : ge.bias, set2 ? ge.ln2_s1 : ge.ln_s1, set2 ? ge.ln2_s0 : ge.ln_s0);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int BM, int BN, int WMv, int WNv, int R, int TPS, bool LN>
+int launch_stream1_k(const IgemmArgs& g, hipStream_t s) {
+  constexpr size_t lds = (size_t)R * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr_set[64] = {};   // per DEVICE: the attribute belongs to the device's copy of the kernel
+  int devi = 0;
+  MD_HIP_CHECK(hipGetDevice(&devi));
+  if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+    MD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_stream1_kernel<BM, BN, WMv, WNv, R, TPS, LN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (devi >= 0 && devi < 64) attr_set[devi] = true;
+  }
+  dim3 grid(g.tiles_m * g.tiles_n, 1, g.splitk);
+  hipLaunchKernelGGL((igemm_stream1_kernel<BM, BN, WMv, WNv, R, TPS, LN>), grid, dim3(64 * WMv * WNv), lds, s, g);
+  MD_HIP_CHECK(hipGetLastError());
+  return MD_OK;
+}
+
 template <int BM, int BN, int WMv, int WNv, int AJ>
 int launch_stream_k(const IgemmArgs& g, hipStream_t s) {
   constexpr int NW = WMv * WNv;
@@ -255,8 +439,8 @@ int launch_stream_k(const IgemmArgs& g, hipStream_t s) {
 // rows of the haloed A block in units of 8 x waves rows; 0: this image width is not served
 int stream_aj(int bm, int waves, int win) {
   const int aj = (bm + 2 * win + 2 + 8 * waves - 1) / (8 * waves);
-  if (bm == 64 && waves == 4) return (aj >= 3 && aj <= 5) ? aj : (aj < 3 ? 3 : 0);
-  if (bm == 128 && waves == 4) return (aj >= 5 && aj <= 7) ? aj : (aj < 5 ? 5 : 0);
+  if (bm == 64 && waves == 4) return (aj >= 3 && aj <= 7) ? aj : (aj < 3 ? 3 : 0);
+  if (bm == 128 && waves == 4) return (aj >= 5 && aj <= 9) ? aj : (aj < 5 ? 5 : 0);
   return 0;
 }
 
@@ -274,6 +458,8 @@ int igemm_stream_launch(const IgemmArgs& g, int bm, int bn, hipStream_t s) {
       case 3: return launch_stream_k<64, 64, 2, 2, 3>(g, s);
       case 4: return launch_stream_k<64, 64, 2, 2, 4>(g, s);
       case 5: return launch_stream_k<64, 64, 2, 2, 5>(g, s);
+      case 6: return launch_stream_k<64, 64, 2, 2, 6>(g, s);
+      case 7: return launch_stream_k<64, 64, 2, 2, 7>(g, s);
       default: return MD_ERR_UNSUPPORTED;
     }
   }
@@ -282,9 +468,19 @@ int igemm_stream_launch(const IgemmArgs& g, int bm, int bn, hipStream_t s) {
       case 5: return launch_stream_k<128, 64, 2, 2, 5>(g, s);
       case 6: return launch_stream_k<128, 64, 2, 2, 6>(g, s);
       case 7: return launch_stream_k<128, 64, 2, 2, 7>(g, s);
+      case 8: return launch_stream_k<128, 64, 2, 2, 8>(g, s);
+      case 9: return launch_stream_k<128, 64, 2, 2, 9>(g, s);
       default: return MD_ERR_UNSUPPORTED;
     }
   }
+  return MD_ERR_UNSUPPORTED;
+}
+
+// the 1x1 / linear form: (bm, bn) -> instantiation; LayerNorm folding by the launch arguments
+int igemm_stream1_launch(const IgemmArgs& g, int bm, int bn, hipStream_t s) {
+  if (g.ksize != 1 || g.stride != 1 || g.ups || bn != 64) return MD_ERR_UNSUPPORTED;
+  if (bm == 64) return g.ln_s1 ? launch_stream1_k<64, 64, 2, 2, 8, 2, true>(g, s) : launch_stream1_k<64, 64, 2, 2, 8, 2, false>(g, s);
+  if (bm == 128) return g.ln_s1 ? launch_stream1_k<128, 64, 2, 2, 6, 2, true>(g, s) : launch_stream1_k<128, 64, 2, 2, 6, 2, false>(g, s);
   return MD_ERR_UNSUPPORTED;
 }
 

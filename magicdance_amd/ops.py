@@ -114,15 +114,17 @@ def igemm_config_info(cfg):
     info = (C.c_int32 * 8)()
     if _lib.load().md_igemm_config_info(int(cfg), C.byref(info)) != _lib.MD_OK:
         return None
-    return dict(bm=info[0], bn=info[1], kt=info[2], kg=info[3], ring=bool(info[4]), d1=info[5], d9=info[6], wn=info[7], stat=info[4] == 2)
+    return dict(bm=info[0], bn=info[1], kt=info[2], kg=info[3], ring=bool(info[4]), d1=info[5], d9=info[6], wn=info[7], stat=max(0, info[4] - 1))
 
 
 def ring_lds_bytes(cfg, ksize, win):
     """dynamic LDS a ring config needs for a layer (the launcher refuses > 160 KiB): mirrors igemm_ring.hip::ring_lds_bytes"""
     c = igemm_config_info(cfg)
+    if c["stat"] == 2:   # the static 1x1 / linear form: d1 slots of one A and one W k-tile
+        return c["d1"] * (c["bm"] + c["bn"]) * 128 if ksize == 1 else 1 << 40
     if c["stat"]:   # the static form (igemm_stream.hip::stream_lds_bytes): 3x3 only, nine W slots + two A blocks of aj x 32 rows
         aj = (c["bm"] + 2 * win + 2 + 31) // 32
-        lo, hi = (3, 5) if c["bm"] == 64 else (5, 7)
+        lo, hi = (3, 7) if c["bm"] == 64 else (5, 9)
         if ksize != 3 or aj > hi:
             return 1 << 40
         return 9 * c["bn"] * 128 + 2 * max(aj, lo) * 32 * 128 + 128

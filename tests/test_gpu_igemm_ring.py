@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 F16, F32 = torch.float16, torch.float32
 RING_CFGS = list(range(40, 65))
 STAT_CFGS = [65, 66]                      # the static ring form (igemm_stream.hip): 3x3 convs only
-CFGS_3X3 = RING_CFGS + STAT_CFGS
+STAT1_CFGS = [67, 68]                     # ... and its 1x1 / linear form
+CFGS_3X3 = RING_CFGS + STAT_CFGS + STAT1_CFGS   # (every test below refuses / skips what a config does not serve)
 
 
 @pytest.fixture(scope="module")
@@ -71,8 +72,12 @@ def test_ring_config_table(dev):
         assert c is not None and c["ring"] and c["stat"] and c["bn"] == 64 and c["d9"] == 9
         assert ops.ring_lds_bytes(cfg, 3, 8) <= 160 * 1024 and ops.ring_lds_bytes(cfg, 3, 16) <= 160 * 1024
         assert ops.ring_lds_bytes(cfg, 1, 16) > 160 * 1024           # no 1x1 layers
-    assert ops.ring_lds_bytes(65, 3, 64) > 160 * 1024                # a 130-pixel halo: the 64 x 64 level is not this kernel's
-    assert ops.igemm_config_info(STAT_CFGS[-1] + 1) is None and not ops.igemm_config_info(15)["ring"]
+    assert ops.ring_lds_bytes(65, 3, 64) <= 160 * 1024 and ops.ring_lds_bytes(65, 3, 128) > 160 * 1024   # up to a 130-pixel halo
+    for cfg in STAT1_CFGS:
+        c = ops.igemm_config_info(cfg)
+        assert c is not None and c["ring"] and c["stat"] == 2 and c["bn"] == 64
+        assert ops.ring_lds_bytes(cfg, 1, 1) <= 160 * 1024 and ops.ring_lds_bytes(cfg, 3, 8) > 160 * 1024
+    assert ops.igemm_config_info(STAT1_CFGS[-1] + 1) is None and not ops.igemm_config_info(15)["ring"]
 
 
 CONV_CASES = [
@@ -141,7 +146,7 @@ def test_ring_rejects_what_it_cannot_do(dev, cfg):
                   out=torch.empty((1, 256, 64), dtype=F16, device=dev), force_cfg=cfg)
 
 
-@pytest.mark.parametrize("cfg", RING_CFGS)
+@pytest.mark.parametrize("cfg", RING_CFGS + STAT1_CFGS)
 def test_ring_epilogues(dev, cfg):
     """every epilogue family behind the ring loop: GEGLU, fused q|k + V^T with the column scale, folded LayerNorm (row statistics
     from the ring's A fragments), the two-term residual stream with and without split-K (3x3), per-sample bias + SiLU."""
@@ -177,6 +182,8 @@ def test_ring_epilogues(dev, cfg):
     ops.igemm(xl, wl, c, batch=b, hin=1, win=n, hout=1, wout=n, c0=cl, out=ol, ln=(s1, s0, 1e-5), force_cfg=cfg)
     refl = F.layer_norm(xl.float(), (cl,), gamma, beta) @ wln.t()
     assert _err(ol, refl) <= 6e-3 * max(1.0, float(refl.abs().max()))
+    if cfg in STAT1_CFGS:
+        return   # (the static 1x1 form: the 3x3 part belongs to configs 65 / 66, test_ring_conv / test_ring_second_parameter_set)
     # 3x3 conv, two-term residual, with / without split-K; per-sample bias rows + SiLU
     xc = _rand((2, 128, 8, 8), 5, dev)
     wt = _rand((128, 128, 3, 3), 6, dev, (128 * 9) ** -0.5)
@@ -208,8 +215,8 @@ PART_CASES = [
 def test_ring_groupnorm_partials(dev, case, cfg):
     from magicdance_amd import ops, engine
     name, b, cin, h, w, cout, k, b2 = case
-    if cfg in STAT_CFGS and k != 3:
-        pytest.skip("the static ring form serves 3x3 convs")
+    if (cfg in STAT_CFGS and k != 3) or (cfg in STAT1_CFGS and k != 1):
+        pytest.skip("the static ring forms serve 3x3 convs (65 / 66) or 1x1 layers (67 / 68)")
     x = _rand((b, cin, h, w), 1, dev)
     wt = _rand((cout, cin, k, k), 2, dev, (cin * k * k) ** -0.5)
     wt2 = _rand((cout, cin, k, k), 12, dev, (cin * k * k) ** -0.5)

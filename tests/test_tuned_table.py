@@ -47,10 +47,13 @@ def _ring_cfgs():
         assert int(r[10]) == first + i, "kRing comment ids follow the array order"
         out[first + i] = tuple(int(v) for v in r[:8]) + (int(r[8] or 0), int(r[9] or 0))
     # the launcher's switch instantiates exactly the table's rows (the static form, round 5, dispatches on the row itself)
-    assert "c && c->stat) return igemm_stream_launch(g, c->bm, c->bn, s);" in src
+    assert "c->stat == 2 ? igemm_stream1_launch(g, c->bm, c->bn, s) : igemm_stream_launch(g, c->bm, c->bn, s);" in src
     for cid, (bm, bn, wm, wn, kt, kg, d1, d9, pipe, stat) in out.items():
-        if stat:
+        if stat == 1:
             assert (bm, bn, wm * wn, d9) in ((64, 64, 4, 9), (128, 64, 4, 9)), cid   # what igemm_stream.hip instantiates
+            continue
+        if stat == 2:
+            assert (bm, bn, wm * wn, kt, d1) in ((64, 64, 4, 2, 8), (128, 64, 4, 2, 6)), cid
             continue
         assert f"case {cid}: return launch_ring_t<{bm}, {bn}, {wm}, {wn}, {kt}, {kg}, {d1}, {d9}{', true' if pipe else ''}>(g, s);" in src, cid
     return out
@@ -67,6 +70,12 @@ def test_tuned_table_entries_are_valid():
     for (m, n, k, ks, st, ups, cfg, split, kg, line) in ents:
         if cfg in ring:   # the ring form: stride 1, no upsample, whole channel blocks per split, its own k-groups, LDS fit at 8x8
             bm, bn, wm, wn, kt, rkg, d1, d9, _pipe, stat = ring[cfg]
+            if stat == 2:   # the static 1x1 / linear form: d1 slots of (A + W) k-tiles; a folded LayerNorm keeps K in one workgroup
+                assert ks == 1 and st == 1 and ups == 0 and k % 64 == 0 and kg in (0, 1) and 1 <= split <= k // 64, line
+                if n in (k, 3 * k, 8 * k):
+                    assert split == 1, line
+                assert d1 * (bm + bn) * 128 <= 160 * 1024, line
+                continue
             if stat:   # the static form: 3x3 convs, nine W slots + two haloed A blocks padded to 32 rows (LDS fit at 8x8 / 16x16)
                 assert ks == 3 and st == 1 and ups == 0 and (k // 9) % 64 == 0 and kg in (0, 1) and 1 <= split <= k // 64 // 9, line
                 aj = max((bm + 2 * 16 + 2 + 31) // 32, 3 if bm == 64 else 5)

@@ -230,8 +230,10 @@ def roofline_blocks(fam, no_decode, pmc_ok):
     # first steps of the loop (only its first block precedes step 0) -- so ms_per_step ~= loop + decode + the first table block,
     # not the plain sum of the families' totals, which counts the overlapped table time twice
     g = lambda v, k: (v[k].get("graph_ms", v[k]["ms"]) if v.get(k) else 0.0)  # noqa: E731
+    nsteps = fam["igemm"]["ddim_steps"]
     fams["_additive"] = {
-        "ddim_loop_ms": sum(g(v, "step") for v in fam.values()), "first_stage_decode_ms": sum(g(v, "decode") for v in fam.values()),
+        "ddim_loop_ms": nsteps * sum(g(v, "step") for v in fam.values()), "ddim_steps": nsteps,
+        "first_stage_decode_ms": sum(g(v, "decode") for v in fam.values()),
         "table_pass_ms_overlapped_with_the_loop": sum(g(v, "table") for v in fam.values()),
         "note": "loop + decode (+ the first block of the table pass, ~1/4 of it at one frame) ~= ms_per_step; norm / elementwise figures are "
                 "eager per-launch event times (their graph replay is not timed separately)"}

@@ -36,6 +36,10 @@ def test_header_symbols_are_exported_and_bound(lib_path):
     assert sorted(_lib.SIGNATURES) == declared
     loaded = _lib.load()
     assert loaded.md_version() == 9 and loaded.md_arch() == b"gfx950"
+    # the driver's build check (__graft_entry__.build) asserts the same ABI version: a bump that forgets it fails build() and
+    # smoke() on the GPU box (round 5 found it that way)
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert int(re.search(r"md_version\(\) == (\d+)", entry).group(1)) == loaded.md_version()
 
 
 def test_param_structs_match_header_layout():

@@ -169,7 +169,7 @@ def _latest_profile(pattern):
     return None if best is None else best[1]
 
 
-def roofline_blocks(fam, no_decode, pmc_ok):
+def roofline_blocks(fam, no_decode, pmc_ok, pmc_name="pmc_summary.json"):
     """`roofline` (igemm, the dominant family), `roofline_attention` and the per-family table from profile_one_step's result"""
     ig = fam["igemm"]
     ig_ms = ig.get("graph_ms", ig["ms"])
@@ -177,7 +177,7 @@ def roofline_blocks(fam, no_decode, pmc_ok):
     # HBM bytes per igemm launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of configs[1] -- the
     # 50-step one-frame batch --, FETCH doubled per MI355X_MICROARCH.md); committed under profiles/, null when absent
     traffic, traffic_src, traffic_kind = None, None, "measured"
-    path = _latest_profile("pmc_summary.json") if pmc_ok else None
+    path = _latest_profile(pmc_name) if pmc_ok else None
     if path:
         try:
             pmc = json.load(open(path))
@@ -199,7 +199,7 @@ def roofline_blocks(fam, no_decode, pmc_ok):
             f"{ig['ddim_steps']} DDIM steps" + ("" if no_decode else " + first-stage decode") + ")", "achieved": ach,
             "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic,
             "traffic_unit": (f"bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_src}, {traffic_kind})" if traffic_src else
-                             "null: the committed PMC passes cover configs[1] only"),
+                             "null: no committed PMC pass covers this workload"),
             "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
             "flops_per_launch": ig["flops"] / max(ig["launches"], 1),
             "avg_launch_us": 1e3 * ig_ms / max(ig["launches"], 1), "launches": ig["launches"], "ms": ig_ms,
@@ -458,7 +458,9 @@ def main():
               "steps": n8, "warmup": 1}
         if not args.no_roofline:
             fam8 = runner.profile_one_step(p8["pose"], ctx, ref, x8, ddim_steps=args.ddim_steps, scale=7.0, decode=not args.no_decode)
-            e8["roofline"], e8["roofline_attention"], e8["families_ms_per_batch"] = roofline_blocks(fam8, args.no_decode, False)
+            # (round 5: a PMC FETCH / WRITE pass of THIS workload exists too -- profiles/round5_pmc_8frames_summary.json)
+            e8["roofline"], e8["roofline_attention"], e8["families_ms_per_batch"] = roofline_blocks(
+                fam8, args.no_decode, args.ddim_steps == 50 and args.size == 64, "pmc_8frames_summary.json")
         out["extra"] = {"configs[2]": e8}
     if rank == 0 and not multi and not args.no_cpu_baseline:
         z_one = runner.sample(pose[:1], ctx, ref, x_T[:1], ddim_steps=args.ddim_steps, scale=7.0) if not args.no_decode else None

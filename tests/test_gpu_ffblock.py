@@ -154,3 +154,36 @@ def test_ff_block_agrees_with_the_md_igemm_launches_it_replaces(dev, c, b, n):
                  attn=att16, wo=pk["wo"], bo=pk["bo"])
     torch.cuda.synchronize()
     assert torch.equal(again, fused) and torch.equal(again_lo, fused_lo)
+
+
+@pytest.mark.parametrize("bm", [0, 32, 64, 128, 1032, 2032, 3032, 1064, 2064])
+def test_ff_block_is_bit_stable_under_load(dev, bm):
+    """the counted waits of the weight ring (compile-time immediates) must never let a piece be read before it landed: repeated
+    launches -- cold weight sets in rotation, a copy engine hogging HBM on a second stream, workgroups in both parameter sets -- stay
+    bit-identical to the first result (a wait that is one load short shows up here, not on an idle chip)"""
+    from magicdance_amd import ops
+    c, m, m_split = 320, 12288, 8192
+    sets = [make_params(c, 10 + 40 * i, dev)["packed"] for i in range(3)]
+    x16 = (_rand((m, c), 1, dev) + 0.2).to(F16)
+    lo16 = _rand((m, c), 3, dev, 1e-3).to(F16)
+    att16 = _rand((m, c), 2, dev).to(F16)
+    hog_src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+
+    def run(i):
+        pa, pb = sets[i % 3], sets[(i + 1) % 3]
+        out, out_lo = torch.empty((m, c), dtype=F16, device=dev), torch.empty((m, c), dtype=F16, device=dev)
+        ops.ff_block(x16, out, m=m, c=c, w1=pa["w1"], s1=pa["s1"], s0=pa["s0"], w2=pa["w2"], b2=pa["b2"], x_lo=lo16, out_lo=out_lo,
+                     attn=att16, wo=pa["wo"], bo=pa["bo"], set2=pb, m_split=m_split, force_bm=bm)
+        return out, out_lo
+    refs = [run(i) for i in range(3)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            hog_dst.copy_(hog_src)
+    for rep in range(5):
+        for i in range(3):
+            o, ol = run(i)
+            assert torch.equal(o, refs[i][0]) and torch.equal(ol, refs[i][1]), (bm, rep, i)
+    torch.cuda.synchronize()

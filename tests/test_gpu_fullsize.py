@@ -22,10 +22,12 @@ pytestmark = pytest.mark.gpu
 TOL_EPS = 2.6e-3        # one apply_model
 TOL_SEAM = 1e-3         # bank / pose tensors (norm and head slice)
 TOL_GUIDED = 5e-3       # guided eps e_u + 7 (e_c - e_u) on the reference's x_t: CFG 7 combines two evaluations
-# final latent of the free-running loop: 1.25 x the values measured on the round-5 tree (profiles/round5_parity_fullsize.txt: 8.51e-4 /
-# 6.28e-4 / 1.47e-3; the arithmetic is deterministic across boxes) -- rounds 2-4 asserted 2x, which let configs[0] drift from 8.4e-4 to
-# 9.7e-4 unnoticed (round-4 review); a change that moves a trajectory by a quarter now fails here and has to be looked at
-TOL_TRAJ = {"c0_b1_s20": 1.07e-3, "c1_b1_s50": 7.9e-4, "c2_b8_s2": 1.85e-3}
+# final latent of the free-running loop: 1.25 x the values measured on the round-5 tree (profiles/round5_parity_fullsize.txt: 7.91e-4 /
+# 7.47e-4 / 1.54e-3; the arithmetic is deterministic across boxes) -- rounds 2-4 asserted 2x, which let configs[0] drift from 8.4e-4 to
+# 9.7e-4 unnoticed (round-4 review); a change that moves a trajectory by a quarter now fails here and has to be looked at.  (Not
+# tighter: re-tiling 16 small convs and carrying the block tail's stream in fp32 moved c0 / c1 by -7 % / +19 % within round 5 --
+# summation-order noise of a 50-step recurrence.)
+TOL_TRAJ = {"c0_b1_s20": 9.9e-4, "c1_b1_s50": 9.3e-4, "c2_b8_s2": 1.92e-3}
 
 _LOG = []
 
@@ -262,15 +264,15 @@ def test_configs2_batch8_50steps_frames_match_single_frame_references(dev, model
         r = _rel(z8[k:k + 1], g["z"])
         _LOG.append(f"configs[2] B=8 x {steps} steps: frame {k} of the batch vs the reference's single-frame run: rel {r:.3e} "
                     f"(max-abs {np.abs(z8[k:k + 1] - g['z']).max():.3e}, max|z| {np.abs(g['z']).max():.3e})")
-        assert r <= 8.5e-4, (k, r)     # 1.25x the round-5 measurement (6.74e-4 / 6.44e-4)
+        assert r <= 8.8e-4, (k, r)     # 1.25x the round-5 measurement (7.06e-4 / 6.78e-4)
     # alone vs in batch, both on the HIP path
     c1, uc1, x1 = _seq_case(g3, [3], dev)
     z1, _ = model.sample_log(cond=c1, batch_size=1, ddim=True, ddim_steps=steps, eta=0.0, unconditional_guidance_scale=7,
                              unconditional_conditioning=uc1, inpaint=None, x_T=x1)
     r = _rel(z1.cpu().numpy(), z8[3:4])
     _LOG.append(f"configs[2]: frame 3 sampled alone vs inside the batch of 8 (HIP vs HIP, {steps} steps): rel {r:.3e}")
-    assert r <= 6.8e-4, r     # measured 5.37e-4 (summation-order noise between the tile choices of B = 1 and B = 8)
-    assert _rel(z1.cpu().numpy(), g3["z"]) <= 8.5e-4
+    assert r <= 6.8e-4, r     # measured 5.30e-4 (summation-order noise between the tile choices of B = 1 and B = 8)
+    assert _rel(z1.cpu().numpy(), g3["z"]) <= 8.8e-4
 
 
 def test_small_x_T_recurrence_sensitivity(dev, model):
@@ -303,7 +305,7 @@ def test_small_x_T_recurrence_sensitivity(dev, model):
         curve.append(_rel(got, want))
     _LOG.append(f"x_T / 16: guided eps on the reference x_t per step: max {max(curve):.3e} mean {np.mean(curve):.3e}")
     assert max(curve) <= TOL_GUIDED, max(curve)          # a single evaluation is as accurate as at the standard scale ...
-    assert ab / zmax <= 5.9e-3, ab / zmax                # ... the recurrence amplifies it more (measured 4.68e-3; 1.25x)
+    assert ab / zmax <= 5.4e-3, ab / zmax                # ... the recurrence amplifies it more (measured 4.31e-3; 1.25x)
 
 
 # ABSOLUTE tolerance of the realistic-scale case = 2x the measured value (1.31e-2 at max|z| 6.55: profiles/round3_parity_fullsize.txt)
@@ -362,7 +364,7 @@ def test_configs4_geometry_768_matches_reference(dev, model96):
     assert xs.shape == g["x_traj"].shape
     rz = _rel(z.cpu().numpy(), g["z"])
     _LOG.append(f"c4_b1_s2 (768x768): latent after {steps} steps rel {rz:.3e}")
-    assert rz <= 1.95e-3, rz   # measured 1.54e-3
+    assert rz <= 2.1e-3, rz   # measured 1.69e-3
 
 
 def test_configs4_geometry_768_fp8_attention_bound(dev):
@@ -385,4 +387,4 @@ def test_configs4_geometry_768_fp8_attention_bound(dev):
     finally:
         engine.ATTN_FP8 = False
     _LOG.append(f"c4_b1_s2 (768x768) fp8 attention: eps_cond rel {rc:.3e}  eps_uncond rel {ru:.3e}  latent rel {rz:.3e}")
-    assert rc <= 5.2e-3 and ru <= 5.1e-3 and rz <= 7.5e-3, (rc, ru, rz)   # 1.25x the measured 4.13e-3 / 4.04e-3 / 5.97e-3 (rounds 3-4 asserted 2e-2 / 3e-2)
+    assert rc <= 5.1e-3 and ru <= 5.1e-3 and rz <= 7.65e-3, (rc, ru, rz)   # 1.25x the measured 4.05e-3 / 4.10e-3 / 6.12e-3 (rounds 3-4 asserted 2e-2 / 3e-2)

@@ -112,7 +112,9 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
                 if kg <= MAX_KG.get(cfg, 1) and M <= 32768 and nk >= 2 * kg and sp in (1, 2, 3, 4, 6, 8) and nk // (sp * kg) >= 1:
                     cands.append((cfg, sp, kg))
     res = []
-    for cfg, sp, kg in cands:
+    # (round 5: the FIRST timed graph of a shape runs on a chip that idled through the tensor set-up above -- tools/tune_ring.py found a
+    #  config timed against itself at 25.2 vs 13.9 us -- so the first candidate is timed twice and its first timing dropped)
+    for ci, (cfg, sp, kg) in enumerate(cands[:1] + cands):
         if True:
             def run(i=0):
                 ops.igemm(x0, wts[i % ncopy], N, batch=B, hin=h, win=w, hout=ho, wout=wo, c0=c0, ksize=ks, stride=st, ups=up, a1=x1, c1=c1,
@@ -136,7 +138,8 @@ for key, count in sorted(shapes.items(), key=lambda kv: -kv[1]):
                     side.synchronize()
                     us = e0.elapsed_time(e1) / REPS * 1e3
                     g.destroy()
-                res.append((us, cfg, sp, kg))
+                if ci > 0:
+                    res.append((us, cfg, sp, kg))
             except Exception as ex:  # noqa: BLE001
                 print("ERR", key, cfg, sp, kg, ex, flush=True)
     res.sort()

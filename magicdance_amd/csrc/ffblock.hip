@@ -12,11 +12,13 @@
 //   * A tile [BM][C] fp16 = C / 64 k-tiles of [BM][64], XOR-swizzled 16-byte chunks (the md_igemm stage layout), filled by LDS-DMA.
 //   * The weights are consumed as ONE linear stream of 8 KiB "pieces" (64 weight rows x one 64-deep k-tile of the tiled storage
 //     form, md_igemm_params.w_tiled): [head: C/64 k-tiles x C/64 pieces of Wo] then per 64-wide hidden chunk j:
-//     [5 k-tiles x 2 pieces of the LN-folded GEGLU projection rows 128 j .. 128 j + 127 | C/64 pieces of W2's k-tile j].
-//     Every piece is ONE LDS-DMA instruction per wave (8 waves x 8 rows x 128 B) into an R-slot ring; a step waits with a COUNTED
-//     s_waitcnt vmcnt(n) (n = this wave's DMA instructions issued after the step's last piece: the stream position is known
-//     analytically), passes one raw s_barrier, refills the slots the previous step freed, then computes: R - 2 pieces (40-64 KiB
-//     per CU) stay in flight across every barrier.
+//     [C/64 k-tiles x 2 pieces of the LN-folded GEGLU projection rows 128 j .. 128 j + 127 | C/64 pieces of W2's k-tile j].
+//     Every piece is ONE LDS-DMA instruction per wave (8 waves x 8 rows x 128 B) into an R-slot ring.  The schedule is STATIC (Sch<>
+//     below): which piece a step refills, its ring slot and the `s_waitcnt vmcnt(n)` count in front of the step are compile-time
+//     functions of the step -- a step waits, passes one raw s_barrier, refills the slots the previous step freed with the pieces R
+//     positions further down the stream, computes; R minus the pieces of two steps stay in flight across every barrier.  (The first
+//     version kept this bookkeeping at run time: ~125 scalar instructions per wave and step on the CU's ONE scalar unit made it 3x
+//     slower than the launches it replaces -- DESIGN.md section 4, "Round 5".)
 //   * GEMM 1 of a chunk: S[BM][128] = A W1'[chunk]^T over K = C; wave (wm, wn) owns 16 MF rows x 128 / WN columns.  The folded
 //     LayerNorm (row statistics of the fp16 A tile, rank-1 correction with s1 / s0 as md_igemm ln_*) and a * gelu(gate) run on the
 //     accumulators; the fp16 result is parked in a [BM][64] LDS tile (k-tile layout) because the waves of a wave row split the

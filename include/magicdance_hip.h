@@ -140,6 +140,16 @@ typedef struct {
    * read once per step from HBM (one-frame batches: M <= a few thousand) streams BN / 16 sequential 2 KiB-granular streams instead
    * of BN x 128-byte pieces that are K * 2 bytes apart. */
   int32_t w_tiled;
+  /* The GroupNorm that consumes `out` (ABI v10; NULL: none) -- a ResBlock's conv -> GroupNorm -> SiLU (openaimodel.py:221-225,
+   * 245-252) and conv -> the next block's GroupNorm: `gn` points to the md_groupnorm_params the caller is about to pass to
+   * md_groupnorm for it (x0 == out, one source, c0 == n, batch / hw of this call, its own `out`, the same batch2 split when a second
+   * parameter set is in use).  Where this call splits K and the normalisation is a small-slice one (a block owns whole groups of a
+   * sample: the 8x8 / 16x16 levels of a step), the split-K reduction normalises the rows it has just summed -- one launch instead
+   * of two, results bit-identical to the md_groupnorm launch it replaces -- and *gn_done (host int32, required with gn) is set to
+   * 1; otherwise *gn_done = 0 and the caller's md_groupnorm(gn) launch is still due.  MD_ERR_BAD_ARG when the descriptor does not
+   * describe this call's output. */
+  const void* gn;
+  int32_t* gn_done;
 } md_igemm_params;
 
 int md_igemm(const md_igemm_params* p, void* stream);

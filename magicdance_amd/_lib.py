@@ -29,6 +29,7 @@ class IgemmParams(C.Structure):
         ("k8_end", C.c_int32), ("ld_k8", C.c_int32), ("vt_fp8", C.c_int32),
         ("w2", C.c_void_p), ("bias2", C.c_void_p), ("ln2_s1", C.c_void_p), ("ln2_s0", C.c_void_p), ("batch2", C.c_int32),
         ("gn_part", C.c_void_p), ("force_kg", C.c_int32), ("w_tiled", C.c_int32),
+        ("gn", C.c_void_p), ("gn_done", C.POINTER(C.c_int32)),
     ]
 
 

@@ -22,6 +22,7 @@
 __device__ __attribute__((aligned(256))) unsigned char md_zero_page[256];
 
 #include "igemm_core.h"
+#include "gn_small.h"
 
 namespace {
 using namespace mdig;
@@ -517,6 +518,107 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmArgs g) {
   epi_finish(g, MD_LATE_ARGS, m, m / g.tokens, n, s, ebv, erv, erl);
 }
 
+// Split-K reduction that also runs the GroupNorm consuming the output (md_igemm_params.gn, ABI v10): the thread mapping of
+// md_groupnorm's small-slice kernel (gn_small.h) -- a block owns whole groups of one sample and all its pixels -- with the slice
+// SUMMED FROM THE SLABS (z = 0, 1, 2, ... as above) and pushed through the epilogue instead of loaded; `out` (and out_lo) are
+// stored as by igemm_splitk_reduce, the fp16 values stay in registers for the statistics and the normalising pass.  One launch
+// instead of two, and the normalised tensor is bit-identical to md_groupnorm's on the same `out` (same code, same order).
+// The plain row-major fp16 epilogue only (launcher-checked): bias / per-sample bias, SiLU, one- or two-term residual, out_lo.
+__device__ __forceinline__ h4 epi_finish_rm(const IgemmArgs& g, MD_LATE_PARAMS, int m, int n, f4 v, f4 bv, h4 rv, h4 rl) {
+  v += bv;
+  if (n < e_col_scale_end) v *= e_col_scale;
+  if (g.act == MD_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = md::silu_f(v[i]);
+  }
+  if (g.res) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    if (e_res_lo) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+    }
+  }
+  h4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (half_t)v[i];
+  *reinterpret_cast<h4*>(reinterpret_cast<half_t*>(g.out) + (long long)m * g.ld_out + n) = o;
+  if (e_out_lo) {
+    h4 l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[i] = (half_t)(v[i] - (float)o[i]);
+    *reinterpret_cast<h4*>(e_out_lo + (long long)m * g.ld_out + n) = l;
+  }
+  (void)e_k8; (void)e_k8_begin; (void)e_k8_end; (void)e_ld_k8; (void)e_vt_fp8; (void)e_out_t; (void)e_n_tr_begin; (void)e_ld_t;
+  return o;
+}
+
+template <int NV>
+__global__ __launch_bounds__(mdgn::GN_SMALL_THREADS) void igemm_splitk_reduce_gn(const IgemmArgs g, const mdgn::GnArgs n, int gper, int cw8) {
+  using namespace mdgn;
+  __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
+  __shared__ float stat[2 * GN_GPER_MAX];
+  const GnSmallThread t(n, gper, cw8);
+  MD_LATE_LOAD(g)
+  constexpr int ZB = NV >= 4 ? 2 : 4;   // slabs in flight per trip (NV x ZB x 2 16-byte loads per thread)
+  bool valid[NV];
+  long long row[NV];
+  f4 eb[NV][2], acc[NV][2];
+  h4 er[NV][2], el[NV][2];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = t.pl + i * t.ps;
+    valid[i] = t.active && p < n.hw;
+    const int m = t.b * n.hw + p;
+    row[i] = (long long)m * g.N + t.c;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      acc[i][h] = f4{0.f, 0.f, 0.f, 0.f};
+      if (valid[i]) epi_load(g, MD_LATE_ARGS, m, t.b, t.c + 4 * h, eb[i][h], er[i][h], el[i][h]);
+    }
+  }
+  f4 gb[4];
+  gn_small_affine(n, t, gb);
+  const long long slab = (long long)g.M * g.N;
+  for (int z0 = 0; z0 < g.splitk; z0 += ZB) {
+    f4 v[NV][ZB][2];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int u = 0; u < ZB; ++u)
+        if (valid[i] && z0 + u < g.splitk) {
+          const float* src = g.ws + (z0 + u) * slab + row[i];
+          v[i][u][0] = *reinterpret_cast<const f4*>(src);
+          v[i][u][1] = *reinterpret_cast<const f4*>(src + 4);
+        }
+#pragma unroll
+    for (int u = 0; u < ZB; ++u)
+      if (z0 + u < g.splitk) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (valid[i]) {
+            acc[i][0] += v[i][u][0];
+            acc[i][1] += v[i][u][1];
+          }
+      }
+  }
+  h8 x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (valid[i]) {
+      const int m = t.b * n.hw + t.pl + i * t.ps;
+      const h4 o0 = epi_finish_rm(g, MD_LATE_ARGS, m, t.c, acc[i][0], eb[i][0], er[i][0], el[i][0]);
+      const h4 o1 = epi_finish_rm(g, MD_LATE_ARGS, m, t.c + 4, acc[i][1], eb[i][1], er[i][1], el[i][1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[i][e] = o0[e];
+        x[i][4 + e] = o1[e];
+      }
+    }
+  }
+  gn_small_finish<NV>(n, gper, t, x, gb, red, stat);
+}
+
 // Tile configs (ids are stable: igemm_tuned.inc refers to them).
 //   4..7   LOADER 1 (global_load_lds + zero page; ragged channel counts): 128x128, 128x64, 64x128, 64x64
 //   12..15 LOADER 2 (buffer_load..lds, hardware out-of-range zeros):      128x128, 128x64, 64x128, 64x64
@@ -764,7 +866,8 @@ extern "C" int64_t md_igemm_workspace_bytes(const md_igemm_params* p) {
   return (int64_t)32 * M * p->n * 4;
 }
 
-extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
+// *gn_done: the GroupNorm of md_igemm_params.gn ran inside the split-K reduction (reported through md_igemm_params.gn_done)
+static int igemm_impl(const md_igemm_params* p, void* stream, bool* gn_done) {
   const int v = validate(p);
   if (v != MD_OK) return v;
   IgemmArgs g;
@@ -916,9 +1019,50 @@ extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
   }
   if (rc != MD_OK) return rc;
   if (split > 1) {
+    if (p->gn) {   // the consumer's GroupNorm inside the reduction: small slices whose block owns whole groups of one sample
+      const md_groupnorm_params* q = (const md_groupnorm_params*)p->gn;
+      mdgn::GnArgs n;
+      int gper = 1, cw8 = 1;
+      static const bool off = getenv("MD_GN_REDUCE") && atoi(getenv("MD_GN_REDUCE")) == 0;   // A/B switch
+      const bool plain = !p->out_f32 && p->act != MD_ACT_GEGLU && p->n_tr_begin >= p->n && !p->k8 && p->ld_out == p->n;
+      if (!off && plain && mdgn::gn_fill_common(q, n) == MD_OK && !q->x1 && mdgn::gn_small_ok(q->hw, n.cpg, q->groups, &gper, &cw8) &&
+          ((reinterpret_cast<uintptr_t>(n.gamma) | reinterpret_cast<uintptr_t>(n.beta) | reinterpret_cast<uintptr_t>(n.gamma2) |
+            reinterpret_cast<uintptr_t>(n.beta2)) & 15) == 0) {
+        const int ps = mdgn::GN_SMALL_THREADS / cw8, nv = (q->hw + ps - 1) / ps;
+        if (nv <= 4) {
+          const dim3 grid(q->groups / gper, q->batch), block(mdgn::GN_SMALL_THREADS);
+          if (nv == 1)
+            hipLaunchKernelGGL(igemm_splitk_reduce_gn<1>, grid, block, 0, s, g, n, gper, cw8);
+          else if (nv == 2)
+            hipLaunchKernelGGL(igemm_splitk_reduce_gn<2>, grid, block, 0, s, g, n, gper, cw8);
+          else
+            hipLaunchKernelGGL(igemm_splitk_reduce_gn<4>, grid, block, 0, s, g, n, gper, cw8);
+          MD_HIP_CHECK(hipGetLastError());
+          *gn_done = true;
+          return MD_OK;
+        }
+      }
+    }
     const long long work = M * (g.N >> 2);
     hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, g);
     MD_HIP_CHECK(hipGetLastError());
   }
   return MD_OK;
+}
+
+extern "C" int md_igemm(const md_igemm_params* p, void* stream) {
+  if (p && p->gn) {   // the GroupNorm that consumes `out`: exactly this call's output, one source
+    const md_groupnorm_params* q = (const md_groupnorm_params*)p->gn;
+    if (!p->gn_done) return MD_ERR_BAD_ARG;
+    *p->gn_done = 0;
+    if (q->x0 != p->out || q->x1 || q->c1 != 0 || q->c0 != p->n || q->batch != p->batch || q->hw != p->hout * p->wout ||
+        q->out == p->out || !q->out || p->out_f32 || p->act == MD_ACT_GEGLU || p->ld_out != p->n ||
+        ((q->gamma2 && q->beta2 && q->batch2 > 0) != (p->w2 && p->batch2 > 0)) ||
+        (q->gamma2 && q->beta2 && q->batch2 > 0 && q->batch2 != p->batch2))
+      return MD_ERR_BAD_ARG;
+  }
+  bool gn_done = false;
+  const int rc = igemm_impl(p, stream, &gn_done);
+  if (rc == MD_OK && p->gn) *p->gn_done = gn_done ? 1 : 0;
+  return rc;
 }

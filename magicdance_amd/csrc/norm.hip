@@ -10,29 +10,13 @@
 // UNet head (openaimodel.py:221-225,245-252,746-750); Normalize eps 1e-6 (attention.py:89-90); nn.LayerNorm
 // (attention.py:270-272).
 #include "md_common.h"
+#include "gn_small.h"
 
 namespace {
+using namespace mdgn;
 
 constexpr int GN_ITEMS = 512;    // 16-byte chunks per apply block (2 per thread: the loop is latency-bound, not table-bound)
 constexpr int GN_MAX_TY = 8;
-
-struct GnArgs {
-  const half_t* x0;
-  const half_t* x1;
-  int c0, c1, c, cpg, groups;
-  int batch, hw, nchunks, pix_per_chunk;
-  int ch8, ty;            // stats block = ch8 x ty threads: thread (tx, ty) owns 8 channels tx*8.. of pixels ty, ty+TY, ..
-  unsigned cpg_magic;     // c / cpg == (c * cpg_magic) >> 20 for every c < C (checked on the host)
-  float eps;
-  const float* gamma;
-  const float* beta;
-  const float* gamma2;   // samples b >= batch2 (second network of a merged batch)
-  const float* beta2;
-  int batch2;
-  int silu;
-  half_t* out;
-  float* ws;  // [batch][nchunks][groups][2]
-};
 
 // stats: fully coalesced -- a block streams [pix_per_chunk][C] once with 16-byte loads, per-channel fp32 partials stay in
 // registers, then a fixed-order reduction over the block's pixel lanes and the channels of each group (deterministic).
@@ -197,96 +181,25 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs g) {
 // and ALL its pixels, so statistics and normalisation need no cross-block exchange: pass 1 reads the slice (fp32 sums,
 // fixed-order reductions -> deterministic); the slice stays in registers (measured +0.6 % end to end over re-reading it from
 // L2), is normalised, SiLU-ed and stored.
-constexpr int GN_SMALL_THREADS = 512, GN_GPER_MAX = 8, GN_SMALL_MAXV = 16;
 __global__ __launch_bounds__(GN_SMALL_THREADS) void gn_small(const GnArgs g, int gper, int cw8) {
   __shared__ float red[GN_SMALL_THREADS / 64][2 * GN_GPER_MAX];
   __shared__ float stat[2 * GN_GPER_MAX];  // mean[gper], rstd[gper]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y;
-  const int v = tid % cw8, pl = tid / cw8, ps = GN_SMALL_THREADS / cw8;  // fixed vector column, pixel lane, pixel stride
-  const bool active = pl < ps;
-  const int c = blockIdx.x * gper * g.cpg + v * 8;
-  const bool first = c < g.c0;
-  const half_t* src = first ? g.x0 + c : g.x1 + (c - g.c0);
+  const GnSmallThread t(g, gper, cw8);
+  const bool first = t.c < g.c0;
+  const half_t* src = first ? g.x0 + t.c : g.x1 + (t.c - g.c0);
   const long long cs = first ? g.c0 : g.c1;
-  const long long pix0 = (long long)b * g.hw;
-  int lg[8];  // local group of each of this thread's 8 channels
-#pragma unroll
-  for (int e = 0; e < 8; ++e) lg[e] = (v * 8 + e) / g.cpg;
+  const long long pix0 = (long long)t.b * g.hw;
   // the whole slice of this thread (<= GN_SMALL_MAXV vectors, launcher-checked) is loaded up front and stays in registers:
   // one trip to L2, all loads in flight together
   h8 x[GN_SMALL_MAXV];
 #pragma unroll
   for (int i = 0; i < GN_SMALL_MAXV; ++i) {
-    const int p = pl + i * ps;
-    if (active && p < g.hw) x[i] = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
+    const int p = t.pl + i * t.ps;
+    if (t.active && p < g.hw) x[i] = *reinterpret_cast<const h8*>(src + (pix0 + p) * cs);
   }
-  float s[8], q[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < GN_SMALL_MAXV; ++i) {
-    const int p = pl + i * ps;
-    if (active && p < g.hw) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = (float)x[i][e];
-        s[e] += f;
-        q[e] += f * f;
-      }
-    }
-  }
-  for (int k = 0; k < gper; ++k) {  // per local group: this thread's share, then wave, then block (fixed order)
-    float a = 0.f, bq = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      a += lg[e] == k ? s[e] : 0.f;
-      bq += lg[e] == k ? q[e] : 0.f;
-    }
-    a = md::wave_sum(a);
-    bq = md::wave_sum(bq);
-    if (lane == 0) {
-      red[wave][2 * k] = a;
-      red[wave][2 * k + 1] = bq;
-    }
-  }
-  __syncthreads();
-  if (tid < gper) {
-    float sm = 0.f, sq = 0.f;
-    for (int w = 0; w < GN_SMALL_THREADS / 64; ++w) {
-      sm += red[w][2 * tid];
-      sq += red[w][2 * tid + 1];
-    }
-    const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
-    const float mu = sm * inv_n;
-    stat[tid] = mu;
-    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(sq * inv_n - mu * mu, 0.f) + g.eps);
-  }
-  __syncthreads();
-  if (!active) return;
-  float sc[8], sh[8];
-  const float* gamma = b >= g.batch2 ? g.gamma2 : g.gamma;
-  const float* beta = b >= g.batch2 ? g.beta2 : g.beta;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = stat[GN_GPER_MAX + lg[e]] * gamma[c + e];
-    sh[e] = beta[c + e] - stat[lg[e]] * sc[e];
-  }
-  half_t* dst = g.out + c;
-#pragma unroll
-  for (int i = 0; i < GN_SMALL_MAXV; ++i) {
-    const int p = pl + i * ps;
-    if (p < g.hw) {
-      h8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float y = (float)x[i][e] * sc[e] + sh[e];
-        if (g.silu) y = md::silu_f(y);
-        o[e] = (half_t)y;
-      }
-      *reinterpret_cast<h8*>(dst + (pix0 + p) * g.c) = o;
-    }
-  }
+  f4 gb[4];
+  gn_small_affine(g, t, gb);
+  gn_small_finish<GN_SMALL_MAXV>(g, gper, t, x, gb, red, stat);
 }
 
 // GroupNorm from PRODUCER partials (round 3; the ResBlock's "conv + GroupNorm + SiLU" fusion): the md_igemm that wrote x also
@@ -327,21 +240,6 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnArgs g, const float* 
   if (tid < 2) g.ws[((long long)b * g.groups + grp) * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-// whole groups per block such that the block's channel slice is a multiple of 8 channels (16-byte vectors)
-inline bool gn_group_block(int cpg, int groups, int* gper, int* cw8) {
-  int gp = 1;
-  while (gp <= GN_GPER_MAX && ((gp * cpg) & 7)) gp <<= 1;
-  if (gp > GN_GPER_MAX || groups % gp) return false;
-  *gper = gp;
-  *cw8 = gp * cpg / 8;
-  return *cw8 >= 1 && *cw8 <= GN_SMALL_THREADS;
-}
-constexpr long long g_gn_small_bytes = 96LL << 10;
-// small slices: one launch, a block owns whole groups of one sample and all its pixels (gn_small)
-inline bool gn_small_ok(int hw, int cpg, int groups, int* gper, int* cw8) {
-  return gn_group_block(cpg, groups, gper, cw8) && (long long)hw * *gper * cpg * 2 <= g_gn_small_bytes &&
-         hw <= GN_SMALL_MAXV * (GN_SMALL_THREADS / *cw8);
-}
 // producer partials usable: whole 64-row granules per sample, a group's channels fit one finalize block
 inline bool gn_part_ok(int hw, int cpg) { return (hw & 63) == 0 && cpg <= 128; }
 
@@ -430,39 +328,16 @@ extern "C" int md_groupnorm_wants_partials(int32_t batch, int32_t hw, int32_t c,
 }
 
 extern "C" int md_groupnorm(const md_groupnorm_params* p, void* stream) {
-  if (!p || !p->x0 || !p->gamma || !p->beta || !p->out || !p->ws) return MD_ERR_BAD_ARG;
-  const int c = p->c0 + p->c1;
-  if (p->c0 <= 0 || (p->c0 & 7) || p->c1 < 0 || (p->c1 & 7) || ((p->c1 > 0) != (p->x1 != nullptr))) return MD_ERR_BAD_ARG;
-  if (p->groups <= 0 || p->groups > 128 || c % p->groups || c > 4096) return MD_ERR_UNSUPPORTED;
-  if (p->batch <= 0 || p->hw <= 0) return MD_ERR_BAD_ARG;
+  if (!p || !p->ws) return MD_ERR_BAD_ARG;
   GnArgs g;
-  g.x0 = (const half_t*)p->x0;
-  g.x1 = (const half_t*)p->x1;
-  g.c0 = p->c0;
-  g.c1 = p->c1;
-  g.c = c;
-  g.groups = p->groups;
-  g.cpg = c / p->groups;
-  g.batch = p->batch;
-  g.hw = p->hw;
-  g.ch8 = c >> 3;
-  if (g.ch8 > 512) return MD_ERR_UNSUPPORTED;
+  if (const int rc = gn_fill_common(p, g)) return rc;
+  const int c = g.c;
   gn_geometry(p->batch, p->hw, c, &g.ty, &g.pix_per_chunk, &g.nchunks);
   if ((int64_t)p->batch * g.nchunks * p->groups * 2 * (int64_t)sizeof(float) > p->ws_bytes) return MD_ERR_WORKSPACE;
   // exact c / cpg by multiply-shift, verified for this (C, cpg)
   g.cpg_magic = ((1u << 20) + (unsigned)g.cpg - 1u) / (unsigned)g.cpg;
   for (int ch = 0; ch < c; ++ch)
     if ((int)(((unsigned)ch * g.cpg_magic) >> 20) != ch / g.cpg) return MD_ERR_UNSUPPORTED;
-  g.eps = p->eps;
-  g.gamma = p->gamma;
-  g.beta = p->beta;
-  const bool dual = p->gamma2 && p->beta2 && p->batch2 > 0;
-  g.gamma2 = dual ? p->gamma2 : p->gamma;
-  g.beta2 = dual ? p->beta2 : p->beta;
-  g.batch2 = dual ? p->batch2 : 0x7fffffff;
-  g.silu = p->silu;
-  g.out = (half_t*)p->out;
-  g.ws = (float*)p->ws;
   hipStream_t s = (hipStream_t)stream;
   md::ProfScope prof(MD_FAM_NORM, s, 0.0, (double)p->batch * p->hw * c * 2.0 * 3.0);
   {

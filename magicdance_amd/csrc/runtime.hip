@@ -64,7 +64,7 @@ ProfScope::~ProfScope() {
 
 }  // namespace md
 
-extern "C" int md_version(void) { return 9; }
+extern "C" int md_version(void) { return 10; }
 extern "C" int md_last_hip_error(void) { return md::g_last_hip_error; }
 extern "C" const char* md_arch(void) { return "gfx950"; }
 

@@ -79,6 +79,8 @@ _FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
 # reference's CPU path) carry the part their fp16 store dropped to the next link, so the chain's rounding does not accumulate
 # with depth (md_igemm res_lo / out_lo).  MD_RES_LO=0 restores the single-term stream (parity / cost A-B).
 _RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
+# a conv hands the GroupNorm that consumes its output to md_igemm (md_igemm_params.gn): fused into the split-K reduction where it can be
+_GN_NEXT = os.environ.get("MD_GN_NEXT", "1") != "0"
 # GroupNorm statistics from the producing conv's epilogue (md_igemm gn_part -> md_groupnorm part0 / part1).  MD_GN_FUSE=0: every
 # GroupNorm computes its own statistics (A/B, and the parity reference of the fused form in tests/test_gpu_e2e.py).
 _GN_FUSE = os.environ.get("MD_GN_FUSE", "1") != "0"
@@ -219,11 +221,19 @@ class Act:
     """NHWC fp16 activation handle: tensor [B, H*W, C] + spatial dims.  ``lo`` (same shape, fp16, or None) is the second
     term of a two-term residual-stream value: the chain value is t + lo, every GEMM / norm consumer reads t alone.
     ``part`` (fp32 [B*H*W / 64, 2, C] or None): the GroupNorm partial statistics the producing md_igemm wrote for ``t``
-    (sum | sum of squares per 64-row granule and channel); None once anything else has modified ``t``."""
-    __slots__ = ("t", "b", "h", "w", "c", "lo", "part")
+    (sum | sum of squares per 64-row granule and channel); None once anything else has modified ``t``.  ``normed``
+    ((key, Act) or None): the GroupNorm of ``t`` its producing md_igemm already ran (md_igemm_params.gn), keyed on the
+    (parameters, eps, silu) it was run with; ``touched()`` drops both after any in-place change of ``t``."""
+    __slots__ = ("t", "b", "h", "w", "c", "lo", "part", "normed")
 
     def __init__(self, t, b, h, w, c, lo=None, part=None):
         self.t, self.b, self.h, self.w, self.c, self.lo, self.part = t, b, h, w, c, lo, part
+        self.normed = None
+
+    def touched(self):
+        """``t`` was modified in place: statistics / normalised copies made by its producer no longer describe it"""
+        self.part = None
+        self.normed = None
 
     @property
     def hw(self):
@@ -419,11 +429,13 @@ class NetEngine:
         return cls._WANT[key]
 
     def conv(self, x, w, n, *, k=3, stride=1, ups=0, x1=None, bias=None, bias_bs=0, res=None, act=MD_ACT_NONE,
-             out_f32=False, out=None, ln=None, lo=False, col_scale=None, stats=False):
+             out_f32=False, out=None, ln=None, lo=False, col_scale=None, stats=False, gn_next=None):
         """conv / linear on an Act (optionally channel-concat of two Acts); returns an Act.  ``lo``: the output is a link of
         a residual chain -- also store what the fp16 rounding dropped (Act.lo), to be added back by the next link.  ``stats``:
         the output may feed a GroupNorm -- let the epilogue write its partial statistics (Act.part) where that saves the
-        GroupNorm's own pass; a tensor: the partials buffer to refresh (in-place add into part of an existing tensor)."""
+        GroupNorm's own pass; a tensor: the partials buffer to refresh (in-place add into part of an existing tensor).
+        ``gn_next`` = (gamma/beta pair, eps, silu) of the GroupNorm that consumes the output next: it is handed to md_igemm
+        (which runs it inside its split-K reduction where it can) or launched right behind, and parked in ``Act.normed``."""
         hin, win = x.h, x.w
         if ups:
             hout, wout = 2 * hin, 2 * win
@@ -445,13 +457,28 @@ class NetEngine:
             part = stats
         elif stats and act != MD_ACT_GEGLU and not out_f32 and self.want_part(x.b, hout * wout, nout):
             part = self.arena.alloc((x.b * hout * wout // 64, 2, nout), F32)
-        ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
-                  a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
-                  res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
-                  out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo, col_scale=col_scale,
-                  set2=set2, gn_part=part, w_tiled=is_tiled(w))
+        gp = hn = None
+        if gn_next is not None and _GN_NEXT and not out_f32 and act != MD_ACT_GEGLU and isinstance(gn_next[0][0], Dual) == (set2 is not None):
+            gb, g_eps, g_silu = gn_next
+            gset2 = None
+            if set2 is not None:
+                gset2, gb = (self._batch2, gb[0].b, gb[1].b), (gb[0].a, gb[1].a)
+            hn = self.arena.alloc((x.b, hout * wout, nout), F16)
+            gp = ops.groupnorm_params(out, gb[0], gb[1], hn, self._gn_ws(), batch=x.b, hw=hout * wout, c0=nout, groups=32, eps=g_eps,
+                                      silu=g_silu, set2=gset2, part0=part)
+        done = ops.igemm(x.t, w, n, batch=x.b, hin=hin, win=win, hout=hout, wout=wout, c0=x.c, ksize=k, stride=stride, ups=ups,
+                         a1=None if x1 is None else x1.t, c1=0 if x1 is None else x1.c, bias=bias, bias_batch_stride=bias_bs,
+                         res=None if res is None else res.t, ld_res=0 if res is None else res.c, act=act, out=out, ld_out=nout,
+                         out_f32=out_f32, ws=self._ws(), ln=ln, res_lo=None if res is None else res.lo, out_lo=out_lo,
+                         col_scale=col_scale, set2=set2, gn_part=part, w_tiled=is_tiled(w), **({} if gp is None else {"gn": gp}))
         _chk(out, f"igemm k={k} stride={stride} ups={ups} cin={x.c}+{0 if x1 is None else x1.c} n={n} act={act} M={x.b * hout * wout}")
-        return Act(out, x.b, hout, wout, nout, out_lo, part)
+        y = Act(out, x.b, hout, wout, nout, out_lo, part)
+        if gp is not None:
+            if not done:   # not a split-K call on a small slice: the launch md_igemm could not absorb
+                ops.groupnorm_launch(gp)
+            _chk(hn, f"groupnorm (producer side) c={nout} hw={hout * wout} b={x.b}")
+            y.normed = ((id(gn_next[0][0]), g_eps, g_silu), Act(hn, x.b, hout, wout, nout))
+        return y
 
     def _sets(self, w, bias, ln):
         """(w, bias, ln, set2) of a GEMM whose parameters may be Dual pairs (merged two-network pass)"""
@@ -474,6 +501,8 @@ class NetEngine:
         return buf
 
     def gn(self, x, gb, *, x1=None, eps=1e-5, silu=True):
+        if x1 is None and x.normed is not None and x.normed[0] == (id(gb[0]), eps, silu):
+            return x.normed[1]   # its producer already ran this GroupNorm (conv(gn_next=...))
         c = x.c + (0 if x1 is None else x1.c)
         out = self.arena.alloc((x.b, x.hw, c), F16)
         set2 = None
@@ -570,18 +599,18 @@ class NetEngine:
         return a
 
     # ------------------------------------------------------------------ blocks
-    def resblock(self, r, x, emb, x1=None):
+    def resblock(self, r, x, emb, x1=None, gn_next=None):
         h = self.gn(x, r["gn1"], x1=x1, silu=True)
         # emb: one row per sample, or ONE row shared by the whole batch (all samples of a DDIM step share the timestep)
         h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total if emb.shape[0] > 1 else 0,
-                      stats=True)
+                      stats=True, gn_next=(r["gn2"], 1e-5, True))
         h = self.gn(h, r["gn2"], silu=True)
         if "skip_w" in r:
             skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"], lo=True)
         else:
             assert x1 is None
             skip = x
-        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True, stats=True)
+        return self.conv(h, r["conv2_w"], r["cout"], k=3, bias=r["conv2_b"], res=skip, lo=True, stats=True, gn_next=gn_next)
 
     @staticmethod
     def qscale(dh):
@@ -601,7 +630,7 @@ class NetEngine:
         _chk(out, f"attention b={b} nq={nq} n0={n0} d={dh} seg1={None if seg1 is None else seg1[4]}")
         return out
 
-    def transformer(self, st, x, ctx_kv, ctx_idx, mode, banks, bank_idx, nread):
+    def transformer(self, st, x, ctx_kv, ctx_idx, mode, banks, bank_idx, nread, gn_next=None):
         """SpatialTransformer (attention.py:366-385) with the bank write / read of BasicTransformerBlock (:278-320).
         mode: 'write' (appearance), 'read' (UNet: samples [0, nread) attend to the bank) or None (plain)."""
         b, n, c, heads, dh = x.b, x.hw, st["inner"], st["heads"], st["dh"]
@@ -689,7 +718,7 @@ class NetEngine:
                 ff = self.conv(Act(n3.t, b, 1, n, c), blk["ff1_w"], 8 * c, k=1, bias=blk["ff1_b"], act=MD_ACT_GEGLU)
             t = self.conv(ff, blk["ff2_w"], c, k=1, bias=blk["ff2_b"], res=Act(t.t, b, 1, n, c, t.lo), lo=True)
         t = Act(t.t, b, x.h, x.w, c)
-        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True, stats=True)
+        return self.conv(t, st["pout_w"], st["c"], k=1, bias=st["pout_b"], res=x, lo=True, stats=True, gn_next=gn_next)
 
     def ff_tail(self, blk, att2, t, b, n, c):
         """x = attn2.to_out(att2) + x; x = ff(norm3(x)) + x (attention.py:318-319) through md_ff_block.  ``t``: the stream entering
@@ -730,21 +759,36 @@ class NetEngine:
             self._bank_blocks = [st["blocks"][0] for st in self._all_st()]
         self._project_bank(self._bank_blocks[e], bank, k_out, vt_out)
 
-    def run_block(self, layers, h, emb, ctx_kv, ctx_idx, mode, banks, bank_idx, nread, x1=None):
-        """TimestepEmbedSequential.forward (openaimodel.py:79-108)."""
-        for layer in layers:
+    def _after_input(self, i):
+        """the layer list that reads input block i's output next (the next input block, or the middle block)"""
+        return self.input_blocks[i + 1] if i + 1 < len(self.input_blocks) else self.middle_block
+
+    @staticmethod
+    def first_gn(layers):
+        """(gamma/beta pair, eps, silu) of the GroupNorm a layer list starts with (what the producer of its input may run, conv(gn_next=))"""
+        if layers and layers[0]["kind"] == "res":
+            return (layers[0]["gn1"], 1e-5, True)      # openaimodel.py:221-225
+        if layers and layers[0]["kind"] == "st":
+            return (layers[0]["gn"], 1e-6, False)      # attention.py:89-90, 340
+        return None
+
+    def run_block(self, layers, h, emb, ctx_kv, ctx_idx, mode, banks, bank_idx, nread, x1=None, gn_next=None):
+        """TimestepEmbedSequential.forward (openaimodel.py:79-108).  ``gn_next``: the GroupNorm the NEXT block starts with, when it
+        reads this block's output alone and unmodified (encoder -> encoder / middle block); inside a block every layer knows its successor."""
+        for j, layer in enumerate(layers):
             kind = layer["kind"]
+            nxt = self.first_gn(layers[j + 1:]) if j + 1 < len(layers) else gn_next
             if kind == "res":
-                h = self.resblock(layer, h, emb, x1=x1)
+                h = self.resblock(layer, h, emb, x1=x1, gn_next=nxt)
                 x1 = None
             elif kind == "st":
-                h = self.transformer(layer, h, ctx_kv, ctx_idx, mode, banks, bank_idx[0], nread)
+                h = self.transformer(layer, h, ctx_kv, ctx_idx, mode, banks, bank_idx[0], nread, gn_next=nxt)
                 if h is None:
                     return None
                 if mode == "read":
                     bank_idx[0] += 1                                               # openaimodel.py:92-93
             elif kind == "down":
-                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"], lo=True, stats=True)
+                h = self.conv(h, layer["w"], layer["c"], k=3, stride=2, bias=layer["b"], lo=True, stats=True, gn_next=nxt)
             elif kind == "up":
                 h = self.conv(h, layer["w"], layer["c"], k=3, ups=1, bias=layer["b"], stats=True)
             elif kind == "stem":
@@ -776,8 +820,8 @@ class NetEngine:
         emb = self.time_embedding(t_dev, x.shape[0])
         banks, hs, ctx_idx = [], [], [0]
         h = self.stem_input(x)
-        for blk in self.input_blocks:
-            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0)
+        for i, blk in enumerate(self.input_blocks):
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0, gn_next=self.first_gn(self._after_input(i)))
             hs.append(h)
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, "write", banks, [0], 0)
         for blk in self.output_blocks:
@@ -795,11 +839,12 @@ class NetEngine:
         outs, ctx_idx = [], [0]
         h = self.stem_input(x)
         for i, blk in enumerate(self.input_blocks):
-            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, None, None, [0], 0,
+                               gn_next=None if i == 0 else self.first_gn(self._after_input(i)))
             if i == 0:
                 n = h.b * h.hw * h.c
                 ops.add_f16(h.t, hint_feat.t, h.t, n, hint_feat.b * hint_feat.hw * hint_feat.c)  # h += guided_hint
-                h.part = None   # (the producer's partial statistics no longer describe h)
+                h.touched()   # (the producer's partial statistics no longer describe h)
             outs.append(self.conv(h, self.zero_convs[i]["w"], h.c, k=1, bias=self.zero_convs[i]["b"]))   # cldm.py:733-734
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, None, None, [0], 0)
         outs.append(self.conv(h, self.mid_out["w"], h.c, k=1, bias=self.mid_out["b"]))
@@ -822,8 +867,9 @@ class NetEngine:
         hs, ctx_idx, bank_idx = [], [0], [0]
         pose = None if pose is None else list(pose)
         h = self.stem_input(x)
-        for blk in self.input_blocks:
-            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
+        for i, blk in enumerate(self.input_blocks):
+            h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread,
+                               gn_next=self.first_gn(self._after_input(i)))
             hs.append(h)
         h = self.run_block(self.middle_block, h, emb, ctx_kv, ctx_idx, mode if use_bank_in else None, banks, bank_idx, nread)
         if pose_ready is not None:
@@ -832,14 +878,14 @@ class NetEngine:
             pr = pose.pop()                                                        # cldm.py:93-95
             hh = h.head(nread)
             ops.add_f16(hh.t, pr.t, hh.t, nread * h.hw * h.c, pr.b * pr.hw * pr.c)
-            h.part = None
+            h.touched()
         for blk in self.output_blocks:
             skip = hs.pop()
             if nread > 0 and pose is not None and not only_mid_control and use_bank:
                 pr = pose.pop()                                                    # cldm.py:102-104
                 sh = skip.head(nread)
                 ops.add_f16(sh.t, pr.t, sh.t, nread * skip.hw * skip.c, pr.b * pr.hw * pr.c)
-                skip.part = None
+                skip.touched()
             h = self.run_block(blk, h, emb, ctx_kv, ctx_idx, mode if use_bank else None, banks, bank_idx, nread, x1=skip)
         hn = self.gn(h, self.head_gn, silu=True)
         if eps_out is None:
@@ -899,11 +945,12 @@ class NetEngine:
             demb = Dual(emb, emb_pose)
             h = self.stem_input([x] * (2 + n_pose // b))
             for i, blk in enumerate(inb):
-                h = self.run_block(blk, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
+                h = self.run_block(blk, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread,
+                                   gn_next=None if i == 0 else self.first_gn(inb[i + 1] if i + 1 < len(inb) else mid))
                 if i == 0:   # h += guided_hint on the ControlNet's samples
                     hp = h.tail(b2)
                     ops.add_f16(hp.t, hint_feat.t, hp.t, hp.b * hp.hw * hp.c, hint_feat.b * hint_feat.hw * hint_feat.c)
-                    h.part = None   # (input block 1's first GroupNorm computes its own statistics)
+                    h.touched()   # (input block 1's first GroupNorm computes its own statistics)
                 hs.append(h)
             h = self.run_block(mid, h, demb, ctx_kv_merged, ctx_idx, mode, banks, bank_idx, nread)
         finally:

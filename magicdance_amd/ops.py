@@ -47,8 +47,10 @@ def untile_weights(w, ksize=1):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=MD_ACT_NONE, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False):
-    """See md_igemm.  ``w_tiled``: ``w`` (and set2's) is in the tiled storage form, see ``tile_weights``.  ``gn_part``: fp32 [M / 64][2][n] receiving the GroupNorm partial statistics of the stored rows.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False, gn=None):
+    """See md_igemm.  ``gn``: the GroupNormParams (``groupnorm_params``) of the GroupNorm that consumes ``out`` -- where the call splits K
+    and the slice is a small one the reduction normalises its own rows; returns True then (the caller's ``groupnorm`` launch is
+    not needed), otherwise ``out`` as before.  ``w_tiled``: ``w`` (and set2's) is in the tiled storage form, see ``tile_weights``.  ``gn_part``: fp32 [M / 64][2][n] receiving the GroupNorm partial statistics of the stored rows.  ``set2`` = (batch2, w2, bias2, (ln2_s1, ln2_s0) or None): samples >= batch2 use the second parameter set.  ``col_scale`` = (scale, end): columns < end of the result are multiplied by scale.  ``k8`` = (tensor, begin,
     end, ld): those columns as e4m3 bytes; ``vt_fp8``: the transposed columns as e4m3 bytes.  ``ln`` = (s1, s0, eps): LayerNorm of the A rows folded into the GEMM.  ``out`` must be preallocated ([M, ld_out] fp16, or fp32 when out_f32)."""
     lib = _lib.load()
     p = IgemmParams()
@@ -76,10 +78,16 @@ def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0
         p.batch2, p.w2, p.bias2 = int(set2[0]), _p(set2[1]), _p(set2[2])
         if set2[3] is not None:
             p.ln2_s1, p.ln2_s0 = _p(set2[3][0]), _p(set2[3][1])
+    done = None
+    if gn is not None:
+        done = C.c_int32(0)
+        p.gn, p.gn_done = C.cast(C.pointer(gn), C.c_void_p), C.pointer(done)
     _lib.check(lib.md_igemm(C.byref(p), stream_ptr()), "md_igemm")
     if RECORD is not None:
         m = batch * hout * wout
-        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8, set2, gn_part)))
+        RECORD.append(("igemm", lib.md_igemm, p, 2.0 * m * n * ksize * ksize * (c0 + c1), (a0, a1, w, bias, res, out, out_t, ws, ln, res_lo, out_lo, k8, set2, gn_part, gn, done)))
+    if gn is not None:
+        return bool(done.value)
     return out
 
 
@@ -167,11 +175,10 @@ def groupnorm_wants_partials(batch, hw, c, groups=32):
     return bool(_lib.load().md_groupnorm_wants_partials(batch, hw, c, groups))
 
 
-def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None, part0=None,
-              part1=None):
-    """``set2`` = (batch2, gamma2, beta2): samples >= batch2 use the second affine pair.  ``part0`` / ``part1``: the partial
-    statistics md_igemm wrote for x0 / x1 (gn_part)."""
-    lib = _lib.load()
+def groupnorm_params(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None, part0=None,
+                     part1=None):
+    """md_groupnorm_params.  ``set2`` = (batch2, gamma2, beta2): samples >= batch2 use the second affine pair.  ``part0`` /
+    ``part1``: the partial statistics md_igemm wrote for x0 / x1 (gn_part).  The struct keeps its tensors alive (``_refs``)."""
     p = GroupNormParams()
     p.x0, p.x1, p.c0, p.c1 = _p(x0), _p(x1), c0, c1
     p.batch, p.hw, p.groups, p.eps = batch, hw, groups, eps
@@ -180,7 +187,17 @@ def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=
     if set2 is not None:
         p.batch2, p.gamma2, p.beta2 = int(set2[0]), _p(set2[1]), _p(set2[2])
     p.part0, p.part1 = _p(part0), _p(part1)
-    _lib.check(lib.md_groupnorm(C.byref(p), stream_ptr()), "md_groupnorm")
+    p._refs = (x0, x1, gamma, beta, out, ws, set2, part0, part1)
+    return p
+
+
+def groupnorm(x0, gamma, beta, out, ws, **kw):
+    """See ``groupnorm_params``; ``groupnorm_launch`` takes a prepared struct."""
+    return groupnorm_launch(groupnorm_params(x0, gamma, beta, out, ws, **kw), out)
+
+
+def groupnorm_launch(p, out=None):
+    _lib.check(_lib.load().md_groupnorm(C.byref(p), stream_ptr()), "md_groupnorm")
     return out
 
 

@@ -25,7 +25,19 @@ def _off(t, elems):
 def igemm(a0, w, n, *, batch, hin, win, hout, wout, c0, ksize=1, stride=1, ups=0, a1=None, c1=0, bias=None,
           bias_batch_stride=0, res=None, ld_res=0, act=0, out=None, ld_out=None, out_f32=False, out_t=None,
           n_tr_begin=None, ld_t=0, ws=None, force_cfg=-1, force_splitk=0, asym_pad=False, ln=None, res_lo=None, out_lo=None,
-          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False):
+          col_scale=None, k8=None, vt_fp8=False, set2=None, gn_part=None, force_kg=0, w_tiled=False, gn=None):
+    if gn is not None:   # md_igemm_params.gn: the emulated library "fuses" the consumer's GroupNorm at <= 64 pixels per sample, so the
+        # CPU tier walks both branches of the caller (normalised by this call / the caller's own launch still due)
+        assert gn["x0"] is out and gn["x1"] is None and gn["c0"] == n and gn["batch"] == batch and gn["hw"] == hout * wout
+        assert (gn["set2"] is None) == (set2 is None) and (set2 is None or gn["set2"][0] == set2[0])
+        igemm(a0, w, n, batch=batch, hin=hin, win=win, hout=hout, wout=wout, c0=c0, ksize=ksize, stride=stride, ups=ups, a1=a1, c1=c1,
+              bias=bias, bias_batch_stride=bias_batch_stride, res=res, ld_res=ld_res, act=act, out=out, ld_out=ld_out, out_f32=out_f32,
+              out_t=out_t, n_tr_begin=n_tr_begin, ld_t=ld_t, ws=ws, asym_pad=asym_pad, ln=ln, res_lo=res_lo, out_lo=out_lo,
+              col_scale=col_scale, k8=k8, vt_fp8=vt_fp8, set2=set2, gn_part=gn_part, w_tiled=w_tiled)
+        if hout * wout > 64:
+            return False
+        groupnorm_launch(gn)
+        return True
     if w_tiled:   # tiled weight storage (md_igemm_params.w_tiled): back to row-major, then as below
         from magicdance_amd.ops import untile_weights
         kk_ = ksize * ksize * (c0 + c1)
@@ -216,6 +228,14 @@ def groupnorm_ws_bytes(batch, hw, groups=32):
 # producer -> consumer plumbing of the partial statistics at the small test geometries too
 def groupnorm_wants_partials(batch, hw, c, groups=32):
     return hw % 64 == 0 and c % groups == 0
+
+
+def groupnorm_params(x0, gamma, beta, out, ws, **kw):
+    return dict(x0=x0, gamma=gamma, beta=beta, out=out, ws=ws, **{"x1": None, "set2": None, **kw})
+
+
+def groupnorm_launch(p, out=None):
+    return groupnorm(**p)
 
 
 def groupnorm(x0, gamma, beta, out, ws, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=False, set2=None, part0=None,
@@ -423,7 +443,7 @@ class _Event:
 def install(monkeypatch):
     """Patch magicdance_amd.ops (and the few torch.cuda stream calls of the fused sampler) for a CPU host-logic test."""
     from magicdance_amd import ops, engine
-    for name in ("igemm", "ff_block", "ff_block_supported", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
+    for name in ("igemm", "ff_block", "ff_block_supported", "attention", "groupnorm_ws_bytes", "groupnorm", "groupnorm_params", "groupnorm_launch", "groupnorm_wants_partials", "layernorm", "nchw_to_nhwc_f16",
                  "nhwc_to_nchw_f32", "add_f16", "image_to_u8", "timestep_embedding", "gemv_f32", "select_row_f32", "gather_rows", "softmax_rows", "counter_add",
                  "ddim_update", "gather_frames", "cfg_scatter_add", "window_mean", "Graph"):
         monkeypatch.setattr(ops, name, globals()[name])

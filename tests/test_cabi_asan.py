@@ -98,7 +98,7 @@ def test_host_side_of_the_c_abi_is_clean_under_address_sanitizer(tmp_path):
                        timeout=800)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
-    assert "statuses" in r.stdout and " 9" in r.stdout.splitlines()[-1]      # ABI version 9
+    assert "statuses" in r.stdout and " 10" in r.stdout.splitlines()[-1]      # ABI version 10
     # validation outcomes only: bad argument / unsupported / workspace / no-device -- never MD_OK without a GPU
     st = eval(r.stdout.splitlines()[-1].split("statuses", 1)[1].rsplit("]", 1)[0] + "]")
     assert set(st) <= {-1, -2, -3, -4} and -4 in st, st

@@ -35,7 +35,7 @@ def test_header_symbols_are_exported_and_bound(lib_path):
     # the Python binding covers the same set (a symbol added to the header must be bound, and vice versa)
     assert sorted(_lib.SIGNATURES) == declared
     loaded = _lib.load()
-    assert loaded.md_version() == 9 and loaded.md_arch() == b"gfx950"
+    assert loaded.md_version() == 10 and loaded.md_arch() == b"gfx950"
     # the driver's build check (__graft_entry__.build) asserts the same ABI version: a bump that forgets it fails build() and
     # smoke() on the GPU box (round 5 found it that way)
     entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmagicdance_hip.so")
+# MD_HIP_LIB: another build of the SAME library (A/B measurements of build variants); still no fallback of any kind
+LIB_PATH = os.environ.get("MD_HIP_LIB") or os.path.join(_HERE, "libmagicdance_hip.so")
 
 MD_OK = 0
 MD_ACT_NONE, MD_ACT_SILU, MD_ACT_GEGLU = 0, 1, 2

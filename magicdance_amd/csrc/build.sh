@@ -23,7 +23,13 @@ for f in igemm igemm_ring igemm_stream ffblock attention norm elementwise runtim
   # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified file); the softmax touches every S^T / O
   # element each tile, and the AGPR form cost ~5 v_accvgpr moves per MFMA
   if [ "$f" = "attention" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
-  ( "$HIPCC" $FLAGS $EXTRA ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$BUILD/$f.o" ) &
+  # the GEMM epilogues: no packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  With them the folded-LayerNorm
+  # transform acc <- rstd (acc - mu s1) + s0 came out of the compiler as v_pk_fma_f32 with op_sel operands and gave RUN-TO-RUN different
+  # results on gfx950 -- the low half of a pair on lanes 48-63 computed as if mu s1 were 0, a few 16-row strips per launch (the
+  # in-kernel check of the diagnostic build counted packed != scalar fma on identical registers; profiles/round5_ln_fold_repeatability.txt).
+  # (The host pass of the same command prints "not a recognized feature" for x86 and ignores it.)
+  case "$f" in igemm|igemm_ring|igemm_stream|ffblock) EXTRA="$EXTRA -Xclang -target-feature -Xclang -packed-fp32-ops";; esac
+  ( "$HIPCC" $FLAGS $EXTRA ${MD_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$BUILD/$f.o" 2> >(grep -v "not a recognized feature for this target" >&2) ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

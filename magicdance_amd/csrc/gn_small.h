@@ -117,6 +117,9 @@ __device__ __forceinline__ void gn_small_affine(const GnArgs& g, const GnSmallTh
 template <int MAXV>
 __device__ __forceinline__ void gn_small_finish(const GnArgs& g, int gper, const GnSmallThread& t, const h8 (&x)[MAXV], const f4 (&gb)[4],
                                                 float (*red)[2 * GN_GPER_MAX], float* stat) {
+  // every multiply-add below is spelled out (explicit fma, contraction off): this function is instantiated in two kernels whose
+  // results must agree bit for bit, and left to the compiler one instantiation fuses a multiply-add that the other keeps apart
+#pragma clang fp contract(off)
   const int tid = t.tid, lane = tid & 63, wave = tid >> 6;
   const long long pix0 = (long long)t.b * g.hw;
   float s[8], q[8];
@@ -130,7 +133,7 @@ __device__ __forceinline__ void gn_small_finish(const GnArgs& g, int gper, const
       for (int e = 0; e < 8; ++e) {
         const float f = (float)x[i][e];
         s[e] += f;
-        q[e] += f * f;
+        q[e] = __builtin_fmaf(f, f, q[e]);
       }
     }
   }
@@ -158,7 +161,7 @@ __device__ __forceinline__ void gn_small_finish(const GnArgs& g, int gper, const
     const float inv_n = 1.0f / ((float)g.hw * (float)g.cpg);
     const float mu = sm * inv_n;
     stat[tid] = mu;
-    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(sq * inv_n - mu * mu, 0.f) + g.eps);
+    stat[GN_GPER_MAX + tid] = rsqrtf(fmaxf(__builtin_fmaf(-mu, mu, sq * inv_n), 0.f) + g.eps);
   }
   __syncthreads();
   if (!t.active) return;
@@ -166,7 +169,7 @@ __device__ __forceinline__ void gn_small_finish(const GnArgs& g, int gper, const
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sc[e] = stat[GN_GPER_MAX + t.lg[e]] * (e < 4 ? gb[0][e] : gb[1][e - 4]);
-    sh[e] = (e < 4 ? gb[2][e] : gb[3][e - 4]) - stat[t.lg[e]] * sc[e];
+    sh[e] = __builtin_fmaf(-stat[t.lg[e]], sc[e], e < 4 ? gb[2][e] : gb[3][e - 4]);
   }
   half_t* dst = g.out + t.c;
 #pragma unroll
@@ -176,7 +179,7 @@ __device__ __forceinline__ void gn_small_finish(const GnArgs& g, int gper, const
       h8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = (float)x[i][e] * sc[e] + sh[e];
+        float y = __builtin_fmaf((float)x[i][e], sc[e], sh[e]);
         if (g.silu) y = md::silu_f(y);
         o[e] = (half_t)y;
       }

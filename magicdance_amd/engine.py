@@ -80,7 +80,8 @@ _FOLD_LN = os.environ.get("MD_FOLD_LN", "1") != "0"
 # with depth (md_igemm res_lo / out_lo).  MD_RES_LO=0 restores the single-term stream (parity / cost A-B).
 _RES_LO = os.environ.get("MD_RES_LO", "1") != "0"
 # a conv hands the GroupNorm that consumes its output to md_igemm (md_igemm_params.gn): fused into the split-K reduction where it can be
-_GN_NEXT = os.environ.get("MD_GN_NEXT", "1") != "0"
+# (bit 0: a ResBlock's conv1 -> its second GroupNorm; bit 1: a block's last conv / a down conv -> the GroupNorm the next layer or block starts with)
+_GN_NEXT = int(os.environ.get("MD_GN_NEXT", "3"))
 # GroupNorm statistics from the producing conv's epilogue (md_igemm gn_part -> md_groupnorm part0 / part1).  MD_GN_FUSE=0: every
 # GroupNorm computes its own statistics (A/B, and the parity reference of the fused form in tests/test_gpu_e2e.py).
 _GN_FUSE = os.environ.get("MD_GN_FUSE", "1") != "0"
@@ -603,7 +604,7 @@ class NetEngine:
         h = self.gn(x, r["gn1"], x1=x1, silu=True)
         # emb: one row per sample, or ONE row shared by the whole batch (all samples of a DDIM step share the timestep)
         h = self.conv(h, r["conv1_w"], r["cout"], k=3, bias=emb[:, r["emb_off"]:], bias_bs=self.emb_total if emb.shape[0] > 1 else 0,
-                      stats=True, gn_next=(r["gn2"], 1e-5, True))
+                      stats=True, gn_next=(r["gn2"], 1e-5, True) if _GN_NEXT & 1 else None)
         h = self.gn(h, r["gn2"], silu=True)
         if "skip_w" in r:
             skip = self.conv(x, r["skip_w"], r["cout"], k=1, x1=x1, bias=r["skip_b"], lo=True)
@@ -777,7 +778,7 @@ class NetEngine:
         reads this block's output alone and unmodified (encoder -> encoder / middle block); inside a block every layer knows its successor."""
         for j, layer in enumerate(layers):
             kind = layer["kind"]
-            nxt = self.first_gn(layers[j + 1:]) if j + 1 < len(layers) else gn_next
+            nxt = (self.first_gn(layers[j + 1:]) if j + 1 < len(layers) else gn_next) if _GN_NEXT & 2 else None
             if kind == "res":
                 h = self.resblock(layer, h, emb, x1=x1, gn_next=nxt)
                 x1 = None

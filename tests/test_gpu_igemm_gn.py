@@ -51,7 +51,8 @@ def _run(dev, *, b, side, cin, n, k, split, cfg, res, lo, per_sample_bias, silu,
                               set2=(b2, gamma2, beta2) if dual else None)
     kw = dict(batch=b, hin=side, win=side, hout=side, wout=side, c0=cin, ksize=k, bias=bias if per_sample_bias else bias[0],
               bias_batch_stride=n if per_sample_bias else 0, res=r, ld_res=n if res else 0, res_lo=rl, out=out, out_lo=out_lo, ws=ws,
-              force_cfg=cfg, force_splitk=split, set2=set2)
+              force_cfg=cfg, force_splitk=split, set2=set2,
+              force_kg=0 if ops.igemm_config_info(cfg)["ring"] else 1)   # (a forced split stays a split: no in-workgroup k-groups)
     done = None
     if fused:
         done = ops.igemm(x, w, n, gn=gp, **kw)
@@ -68,8 +69,8 @@ def _run(dev, *, b, side, cin, n, k, split, cfg, res, lo, per_sample_bias, silu,
 # a 1x1 with split-K, and a narrow test geometry (cpg = 2: four groups per block)
 SHAPES = [
     (3, 8, 1280, 1280, 3, 4, 65), (2, 8, 2560, 1280, 3, 8, 66), (3, 16, 1280, 1280, 3, 2, 66), (2, 16, 2560, 1280, 3, 3, 66),
-    (2, 16, 1920, 1280, 3, 3, 28), (24, 8, 1280, 1280, 3, 4, 12), (2, 16, 5120, 1280, 1, 4, 29), (2, 8, 64, 64, 3, 3, 15),
-    (3, 16, 640, 1280, 3, 5, 15),
+    (2, 16, 1920, 1280, 3, 3, 28), (24, 8, 1280, 1280, 3, 4, 12), (2, 16, 5120, 1280, 1, 4, 29), (2, 8, 64, 64, 3, 2, 15),
+    (3, 16, 640, 1280, 3, 4, 15),
 ]
 
 
@@ -87,10 +88,18 @@ def test_reduction_with_groupnorm_is_bit_identical_to_the_two_launches(dev, shap
     r = _run(dev, b=b, side=side, cin=cin, n=n, k=k, split=split, cfg=cfg, fused=False, **opt)
     assert a[3] is True, "the library declined a split-K small-slice call"
     assert torch.isfinite(r[2].float()).all() and torch.isfinite(r[0].float()).all()
-    assert torch.equal(a[0], r[0]), "conv output differs"
+
+    def same(u, v, what):
+        if not torch.equal(u, v):
+            d = (u.float() - v.float()).abs()
+            bad = (d > 0) | torch.isnan(d)
+            idx = bad.nonzero()
+            raise AssertionError(f"{what} differs: {int(bad.sum())} of {bad.numel()} elements, max |diff| {float(d[~torch.isnan(d)].max()) if (~torch.isnan(d)).any() else 'nan'}, "
+                                 f"nan {int(torch.isnan(d).sum())}, first {idx[:4].tolist()}, last {idx[-2:].tolist()}")
+    same(a[0], r[0], "conv output")
     if opt["lo"]:
-        assert torch.equal(a[1], r[1]), "second term of the residual stream differs"
-    assert torch.equal(a[2], r[2]), "normalised output differs"
+        same(a[1], r[1], "second term of the residual stream")
+    same(a[2], r[2], "normalised output")
 
 
 @pytest.mark.parametrize("case", ["no_split", "large_slice"])
@@ -117,7 +126,7 @@ def test_calls_the_library_must_decline(dev, case):
     g = torch.ones(n, device=dev)
     gp = ops.groupnorm_params(out, g, g, hn, torch.empty(1 << 20, dtype=torch.uint8, device=dev), batch=b, hw=side * side, c0=n)
     assert ops.igemm(x, w, n, batch=b, hin=side, win=side, hout=side, wout=side, c0=kw["cin"], ksize=3, out=out, ws=ws,
-                     force_cfg=kw["cfg"], force_splitk=kw["split"], gn=gp) is False
+                     force_cfg=kw["cfg"], force_splitk=kw["split"], force_kg=1, gn=gp) is False
     torch.cuda.synchronize()
     assert (hn == 7.0).all()
 
@@ -153,7 +162,7 @@ def test_descriptor_that_does_not_describe_the_output_is_refused(dev):
 
 
 def test_sampler_with_and_without_producer_side_groupnorm_is_bit_identical(dev, monkeypatch):
-    """full SD-1.5 width, one frame, 3 DDIM steps of the fused route (merged UNet + ControlNet pass, captured graph): conv(gn_next=)
+    """full SD-1.5 width, one frame, 4 DDIM steps of the fused route (merged UNet + ControlNet pass, captured graph): conv(gn_next=)
     on (the default) and off give the same latent bit for bit, and the on run did absorb GroupNorm launches into reductions"""
     from magicdance_amd import engine, ops
     g = H.load_golden("c1_b1_s50")
@@ -161,7 +170,7 @@ def test_sampler_with_and_without_producer_side_groupnorm_is_bit_identical(dev, 
     mv = lambda d: {k: ([t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in d.items()}  # noqa: E731
     zs, absorbed = {}, {}
     for on in (True, False):
-        monkeypatch.setattr(engine, "_GN_NEXT", on)
+        monkeypatch.setattr(engine, "_GN_NEXT", 3 if on else 0)
         model = H.build_hip_model(320, 8, seed=0, device=dev, image_size=64)
         n_done = [0]
         orig = ops.igemm
@@ -172,7 +181,7 @@ def test_sampler_with_and_without_producer_side_groupnorm_is_bit_identical(dev, 
                 n_done[0] += 1
             return r
         monkeypatch.setattr(ops, "igemm", counting)
-        z, _ = model.sample_log(cond=mv(inp["c"]), batch_size=1, ddim=True, ddim_steps=3, eta=0.0, unconditional_guidance_scale=7,
+        z, _ = model.sample_log(cond=mv(inp["c"]), batch_size=1, ddim=True, ddim_steps=4, eta=0.0, unconditional_guidance_scale=7,
                                 unconditional_conditioning=mv(inp["uc"]), inpaint=None, x_T=inp["x_T"].to(dev))
         torch.cuda.synchronize()
         monkeypatch.setattr(ops, "igemm", orig)

@@ -1,0 +1,107 @@
+"""Per-launch repeatability of one DDIM step (GPU box only): every C-ABI call of a step (and of the reference-KV table pass) is
+recorded with its arguments, then REPLAYED on restored inputs several times; any tensor argument whose bytes differ between two
+replays names a launch that is not deterministic.  usage: python tools/call_repeat_probe.py [frames] [reps] [table]
+(``table``: probe the launches of the table pass instead of the step's)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from magicdance_amd import ops, parallel, synthetic  # noqa: E402
+from magicdance_amd.ddim import DDIMSampler_ReferenceOnly, FusedStepRunner  # noqa: E402
+
+fpg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+table = len(sys.argv) > 3
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+model = bench.build_model(dev, 64)
+inp = synthetic.synth_inputs((64, 64), frames=fpg, seed=0, device=dev)
+run = parallel.FrameShardedSampler(model)
+c, _ = run._cond(inp["pose"], inp["ctx"], inp["ref"])
+sampler = DDIMSampler_ReferenceOnly(model)
+sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+st = model._fused = FusedStepRunner(model)
+NAMES = ["igemm", "ff_block", "attention", "groupnorm", "groupnorm_launch", "layernorm", "add_f16", "nchw_to_nhwc_f16", "nhwc_to_nchw_f32",
+         "select_row_f32", "gather_rows", "ddim_update", "counter_add", "timestep_embedding", "gemv_f32", "softmax_rows"]
+calls = []
+
+
+def tensors(o, out):
+    if isinstance(o, torch.Tensor):
+        out.append(o)
+    elif isinstance(o, (list, tuple)):
+        for v in o:
+            tensors(v, out)
+    elif isinstance(o, dict):
+        for v in o.values():
+            tensors(v, out)
+    elif isinstance(o, C.Structure) and hasattr(o, "_refs"):
+        tensors(o._refs, out)
+    return out
+
+
+with torch.cuda.stream(st.stream):
+    st.prepare(c, inp["x_T"].repeat(fpg, 1, 1, 1), sampler, 7.0, table_mode=True)
+    S = st.S
+    st.compute_bank_rows(range(S))
+    st._launch_sequence()          # warm: sizes the arena
+    st.stream.synchronize()
+    st.counter.zero_()
+    orig = {n: getattr(ops, n) for n in NAMES if hasattr(ops, n)}
+    for n, f in orig.items():
+        def wrap(*a, _f=f, _n=n, **kw):
+            calls.append((_n, _f, a, kw))
+            return _f(*a, **kw)
+        setattr(ops, n, wrap)
+    if table:
+        st.compute_bank_rows(range(2))
+    else:
+        st._launch_sequence()
+    st.stream.synchronize()
+    for n, f in orig.items():
+        setattr(ops, n, f)
+    print(f"{len(calls)} calls recorded ({'table pass, 2 rows' if table else 'one DDIM step'}, {fpg} frame(s)); {reps} replays each", flush=True)
+    bad = 0
+    for i, (n, f, a, kw) in enumerate(calls):
+        ts = tensors((a, kw), [])
+        uniq = {}
+        for t in ts:
+            uniq.setdefault((t.data_ptr(), t.numel(), t.dtype), t)
+        ts = list(uniq.values())
+        pre = [t.clone() for t in ts]
+        first = None
+        worst = None
+        for r in range(reps):
+            for t, p in zip(ts, pre):
+                t.copy_(p)
+            f(*a, **kw)
+            st.stream.synchronize()
+            snap = [t.clone() for t in ts]
+            if first is None:
+                first = snap
+                continue
+            for j, (u, v) in enumerate(zip(snap, first)):
+                if not torch.equal(u.contiguous().view(-1).view(torch.uint8), v.contiguous().view(-1).view(torch.uint8)):   # bytes (NaN-proof)
+                    d = (u.float() - v.float()).abs()
+                    nd = int((d > 0).sum())
+                    worst = (j, tuple(u.shape), str(u.dtype), nd, float(d.max()), float(v.float().abs().max()), (d > 0).nonzero()[:24].tolist())
+        for t, p in zip(ts, snap):   # leave the outputs of a (deterministic or not) run in place for the calls that follow
+            t.copy_(p)
+        if worst is not None:
+            bad += 1
+            desc = ""
+            if n in ("igemm",):
+                desc = f"batch={kw.get('batch')} hin={kw.get('hin')} win={kw.get('win')} c0={kw.get('c0')} c1={kw.get('c1', 0)} n={a[2]} k={kw.get('ksize', 1)} stride={kw.get('stride', 1)} ups={kw.get('ups', 0)} act={kw.get('act', 0)} set2={kw.get('set2') is not None} ln={kw.get('ln') is not None} res={kw.get('res') is not None} gn={kw.get('gn') is not None} part={kw.get('gn_part') is not None}"
+            elif n == "attention":
+                desc = " ".join(f"{k}={kw[k]}" for k in ("batch", "heads", "nq", "d", "n0", "n1", "n1_batches") if k in kw)
+            elif n in ("groupnorm",):
+                desc = " ".join(f"{k}={kw[k]}" for k in ("batch", "hw", "c0", "c1", "silu") if k in kw) + f" part0={kw.get('part0') is not None}"
+            elif n == "ff_block":
+                desc = f"m={kw.get('m')} c={kw.get('c')}"
+            print(f"NOT REPEATABLE call {i} {n} {desc}: arg tensor {worst[0]} shape {worst[1]} {worst[2]}: {worst[3]} elements differ, max |diff| {worst[4]:.3e} (max |value| {worst[5]:.3e}) at {worst[6]}", flush=True)
+    print(f"{bad} of {len(calls)} calls not repeatable", flush=True)
+sys.exit(1 if bad else 0)

@@ -22,12 +22,14 @@ pytestmark = pytest.mark.gpu
 TOL_EPS = 2.6e-3        # one apply_model
 TOL_SEAM = 1e-3         # bank / pose tensors (norm and head slice)
 TOL_GUIDED = 5e-3       # guided eps e_u + 7 (e_c - e_u) on the reference's x_t: CFG 7 combines two evaluations
-# final latent of the free-running loop: 1.25 x the values measured on the round-5 tree (profiles/round5_parity_fullsize.txt: 7.91e-4 /
-# 7.47e-4 / 1.54e-3; the arithmetic is deterministic across boxes) -- rounds 2-4 asserted 2x, which let configs[0] drift from 8.4e-4 to
+# final latent of the free-running loop, measured on the REPEATABLE round-5 build (profiles/round5_parity_fullsize.txt): 8.29e-4 /
+# 6.48e-4 / 1.72e-3 for c0 / c1 / c2.  (Earlier round-5 figures -- 7.91e-4 / 7.47e-4 / 1.54e-3, then 8.15e-4 / 6.60e-4 / 1.54e-3 -- were
+# single draws of a build whose LayerNorm-folded projections differed from launch to launch; tests/test_gpu_repeatability.py.)  The bounds
+# below are 1.25 x the repeatable values -- rounds 2-4 asserted 2x, which let configs[0] drift from 8.4e-4 to
 # 9.7e-4 unnoticed (round-4 review); a change that moves a trajectory by a quarter now fails here and has to be looked at.  (Not
 # tighter: re-tiling 16 small convs and carrying the block tail's stream in fp32 moved c0 / c1 by -7 % / +19 % within round 5 --
 # summation-order noise of a 50-step recurrence.)
-TOL_TRAJ = {"c0_b1_s20": 9.9e-4, "c1_b1_s50": 9.3e-4, "c2_b8_s2": 1.92e-3}
+TOL_TRAJ = {"c0_b1_s20": 1.04e-3, "c1_b1_s50": 8.1e-4, "c2_b8_s2": 2.15e-3}
 
 _LOG = []
 
@@ -196,8 +198,14 @@ def test_50_step_deviation_against_the_fp16_envelope_small_geometry(dev):
     (model_channels 64, latent 16^2; tests/golden/env16_small_b1_s50.npz): eps pair and x_t after EVERY one of the 50 steps.
     Measured 0.57 - 0.92 of the envelope (profiles/round4_parity_envelope.txt); the end of the trajectory sits AT the envelope --
     another batching of the appearance timesteps (different fp32 summation orders in the split-K layers) moved the last steps to
-    1.02 of it in round 4.  Round 5 (the block tail's residual stream crosses md_ff_block in fp32): 0.64 - 0.90; the bound is the
-    envelope itself with 5 % of room for that summation-order noise."""
+    1.02 of it in round 4.  Round 5: every figure quoted before was ONE DRAW of a build whose LayerNorm-folded projections were not
+    repeatable (this geometry, model_channels 64, takes the fold; tests/test_gpu_repeatability.py) -- 0.90 was measured on it, and
+    1.14 with another attention kernel.  The repeatable build measures 1.11, the same on every run: per evaluation the HIP path is
+    TIGHTER than the reference's fp16 arithmetic (eps pair 0.64 / 0.77 of its deviation), up to step 11 the trajectory stays inside
+    the envelope (<= 1.00), from step 21 on it sits at 1.10 - 1.11 of it (8.95e-4 against 8.06e-4 of max|x| after step 50).  The
+    envelope is one realisation of fp16 rounding noise carried through 50 steps, ours is another: the three builds above put the
+    spread of this ratio at +-12 %, so the bound is 1.2 -- the measured value plus 8 % -- and a change that moves it has to be
+    looked at (the values are deterministic now)."""
     g = H.load_golden("env16_small_b1_s50")
     mc, nh, steps = int(g["geo_model_channels"]), int(g["geo_num_heads"]), int(g["steps"])
     m = H.build_hip_model(mc, nh, seed=0, device=dev, image_size=int(g["side"]))
@@ -243,7 +251,7 @@ def test_50_step_deviation_against_the_fp16_envelope_full_width(dev, model):
     assert worst <= ENVELOPE_SLACK, worst
 
 
-SMALL_ENVELOPE_RATIO = 1.05   # round 5: measured worst ratio 0.90 (round 4: 0.92, and 1.02 under another appearance batching -> its bound was 1.25)
+SMALL_ENVELOPE_RATIO = 1.2    # round 5, repeatable build: measured 1.11 (see the docstring above; round 4 bounded 1.25, the non-repeatable build drew 0.90 - 1.14)
 
 
 def test_configs2_batch8_50steps_frames_match_single_frame_references(dev, model):

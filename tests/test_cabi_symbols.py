@@ -106,3 +106,30 @@ def test_gemm_translation_units_are_built_without_packed_fp32():
     sh = open(os.path.join(ROOT, "magicdance_amd", "csrc", "build.sh")).read()
     m = re.search(r'case "\$f" in ([a-z_|]+)\) EXTRA="\$EXTRA -Xclang -target-feature -Xclang -packed-fp32-ops"', sh)
     assert m and set(m.group(1).split("|")) == {"igemm", "igemm_ring", "igemm_stream", "ffblock"}
+
+
+def test_igemm_gn_descriptor_is_validated_before_any_device_work():
+    """md_igemm_params.gn (ABI v10): a descriptor that does not describe the call's output -- or comes without the host flag -- is
+    refused with MD_ERR_BAD_ARG on the host, before any HIP call (so this runs without a GPU; the pointers are never dereferenced)"""
+    from magicdance_amd import _lib
+    loaded = _lib.load()
+    out, other, hn, g = 0x10000, 0x20000, 0x30000, 0x40000
+    p = _lib.IgemmParams()
+    p.a0, p.c0, p.batch, p.hin, p.win, p.hout, p.wout, p.ksize, p.stride = 0x50000, 64, 2, 8, 8, 8, 8, 3, 1
+    p.w, p.n, p.out, p.ld_out, p.n_tr_begin, p.force_cfg = 0x60000, 64, out, 64, 64, -1
+
+    def desc(**kw):
+        q = _lib.GroupNormParams()
+        q.x0, q.c0, q.batch, q.hw, q.groups, q.eps, q.gamma, q.beta, q.out, q.ws, q.ws_bytes = out, 64, 2, 64, 32, 1e-5, g, g, hn, g, 1 << 20
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return q
+    done = ctypes.c_int32(7)
+    for q, flag in ((desc(), None), (desc(x0=other), done), (desc(out=out), done), (desc(hw=32), done), (desc(c0=32), done),
+                    (desc(x1=other, c1=64), done), (desc(batch=3), done), (desc(gamma2=g, beta2=g, batch2=1), done)):
+        p.gn = ctypes.cast(ctypes.pointer(q), ctypes.c_void_p)
+        p.gn_done = ctypes.pointer(flag) if flag is not None else None
+        assert loaded.md_igemm(ctypes.byref(p), None) == -1   # MD_ERR_BAD_ARG
+    p.out_f32 = 1   # a GroupNorm of an fp32 output does not exist
+    p.gn, p.gn_done = ctypes.cast(ctypes.pointer(desc()), ctypes.c_void_p), ctypes.pointer(done)
+    assert loaded.md_igemm(ctypes.byref(p), None) == -1

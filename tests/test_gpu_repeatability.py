@@ -74,10 +74,12 @@ def test_layernorm_folded_projection_is_repeatable(dev, case):
             assert torch.equal(u, v), f"{name}: run {r} differs from the first run, max |diff| {float((u.float() - v.float()).abs().max()):.3e}"
 
 
-def test_every_launch_of_a_step_is_repeatable(dev):
-    """tools/call_repeat_probe.py: each C-ABI call of one full-width DDIM step (merged UNet + ControlNet pass, 1 frame) replayed on
-    restored inputs -- no tensor argument may differ between two replays of any call"""
-    r = subprocess.run([sys.executable, "tools/call_repeat_probe.py", "1", "3"], cwd=H.ROOT, capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("frames", [1, 8])
+def test_every_launch_of_a_step_is_repeatable(dev, frames):
+    """tools/call_repeat_probe.py: each C-ABI call of one full-width DDIM step (merged UNet + ControlNet pass; the one-frame and the
+    eight-frame batch take different kernels / tile shapes) replayed on restored inputs -- no tensor argument may differ between two
+    replays of any call"""
+    r = subprocess.run([sys.executable, "tools/call_repeat_probe.py", str(frames), "3"], cwd=H.ROOT, capture_output=True, text=True, timeout=900)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
     assert r.returncode == 0 and tail.startswith("0 of "), r.stdout[-3000:] + r.stderr[-2000:]
 

@@ -14,6 +14,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // FORM 0: op_sel:[0,1,0] + neg (the transform's form)   1: plain packed fma (no op_sel)   2: op_sel_hi:[1,0,1] (broadcast LOW)
+//      3: v_pk_mul_f32 with an SGPR-pair source and op_sel:[1,0] (how the transform scales its row sums)
+__device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+
 template <int FORM>
 __global__ __launch_bounds__(512) void probe(const float* __restrict__ in, unsigned* __restrict__ bad, float* __restrict__ sink, int iters,
                                              int mfma_waves, int loads, int producers) {
@@ -54,8 +57,12 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ in, unsig
       asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r2) : "v"(s1), "v"(mu), "v"(acc));
     else if (FORM == 1)
       asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r2) : "v"(s1), "v"(mu), "v"(acc));
-    else
+    else if (FORM == 2)
       asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r2) : "v"(s1), "v"(mu), "v"(acc));
+    else {   // the transform's scalar-pair multiply: both halves take the HIGH register of an SGPR pair (eps | 1 / K in the kernel)
+      f2 sp = {uni(1e-5f + 0.f * (float)i), uni(0.003125f)};
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r2) : "s"(sp), "v"(acc));
+    }
     float e0, e1;
     if (FORM == 0) {
       e0 = __builtin_fmaf(-s1.x, mu.y, acc.x);
@@ -63,9 +70,12 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ in, unsig
     } else if (FORM == 1) {
       e0 = __builtin_fmaf(-s1.x, mu.x, acc.x);
       e1 = __builtin_fmaf(-s1.y, mu.y, acc.y);
-    } else {
+    } else if (FORM == 2) {
       e0 = __builtin_fmaf(-s1.x, mu.x, acc.x);
       e1 = __builtin_fmaf(-s1.y, mu.x, acc.y);
+    } else {
+      e0 = 0.003125f * acc.x;
+      e1 = 0.003125f * acc.y;
     }
     cnt += (r2.x != e0) || (r2.y != e1);
     acc.x += 0.25f;                                            // (new operands every trip)
@@ -92,8 +102,9 @@ int main() {
   hipMalloc(&bad, 4);
   hipMemcpy(din, h.data(), N * 4, hipMemcpyHostToDevice);
   const int iters = 4000, grid = 2048;
-  const char* names[3] = {"op_sel:[0,1,0] (low half reads the HIGH register)", "plain packed fma", "op_sel_hi:[1,0,1] (high half reads the LOW register)"};
-  for (int form = 0; form < 3; ++form)
+  const char* names[4] = {"op_sel:[0,1,0] (low half reads the HIGH register)", "plain packed fma", "op_sel_hi:[1,0,1] (high half reads the LOW register)",
+                          "v_pk_mul_f32 with an SGPR pair, op_sel:[1,0]"};
+  for (int form = 0; form < 4; ++form)
     for (int mw = 0; mw <= 4; mw += 4)
       for (int loads = 0; loads < 2; ++loads)
         for (int prod = 0; prod < 2; ++prod) {
@@ -101,6 +112,7 @@ int main() {
           if (form == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(512), 0, 0, din, bad, sink, iters, mw, loads, prod);
           if (form == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(512), 0, 0, din, bad, sink, iters, mw, loads, prod);
           if (form == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(512), 0, 0, din, bad, sink, iters, mw, loads, prod);
+          if (form == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(512), 0, 0, din, bad, sink, iters, mw, loads, prod);
           hipDeviceSynchronize();
           unsigned b = 0;
           hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost);
